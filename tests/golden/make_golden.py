@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by RUNNING THE REFERENCE'S OWN PYTHON.
+
+Run in the build container only (it imports crowsonkb/style_transfer from /root/reference,
+which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What executes unmodified from the reference: ``num_utils`` (scipy-BLAS helpers, TV / p-norm),
+``optimizers`` (Adam, L-BFGS), ``config_system.parse_args`` and, from ``style_transfer``,
+``CaffeModel.eval_features_tile / eval_features_once / prepare_features / preprocess_images /
+eval_sc_grad_tile / eval_sc_grad / roll``, ``TileWorker.process_one_request``,
+``TileWorkerPool.request / set_contents_and_styles``, ``StyleTransfer.eval_loss_and_grad /
+transfer / transfer_multiscale``.
+
+What is substituted, because it is absent from /root/reference and from this container:
+  * ``caffe``          -> ``oracle.caffe_net`` (pycaffe-shaped shim over numpy Caffe-layer
+                          arithmetic, seeded synthetic weights: no .caffemodel exists offline)
+  * ``average.EWMA``   -> the standard bias-corrected EWMA (same class as oracle.optim.Ewma)
+  * ``shared_ndarray`` -> an in-process stand-in (``.array``, ``.copy()``, ``.unlink()``)
+  * ``pywt``, ``aiohttp_index`` -> empty modules (never called on this path)
+  * worker processes   -> a synchronous in-process queue around the reference's worker method
+
+Only data is written: inputs, arguments and the outputs the reference produced.
+"""
+
+import collections
+import os
+import sys
+import types
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+from oracle import caffe_net  # noqa: E402
+
+
+# ------------------------------------------------------------------ stand-ins for absent deps
+class _SharedNDArray:
+    def __init__(self, array):
+        self.array = array
+
+    @classmethod
+    def copy(cls, arr):
+        return cls(np.array(arr, copy=True))
+
+    def unlink(self):
+        pass
+
+
+class _EWMA:
+    def __init__(self, shape=(), dtype=np.float64, beta=0.9, correct_bias=True):
+        self.beta = beta
+        self.beta_accum = 1 if correct_bias else 0
+        self.value = np.zeros(shape, dtype)
+
+    @classmethod
+    def like(cls, arr, beta=0.9, correct_bias=True):
+        return cls(arr.shape, arr.dtype, beta, correct_bias)
+
+    def get(self):
+        return self.value / (1 - self.beta_accum)
+
+    def update(self, datum):
+        self.beta_accum *= self.beta
+        self.value *= self.beta
+        self.value += (1 - self.beta) * datum
+        return self.get()
+
+
+def install_stubs():
+    for name, attrs in (('pywt', {}), ('aiohttp_index', {'IndexMiddleware': object}),
+                        ('shared_ndarray', {'SharedNDArray': _SharedNDArray}),
+                        ('average', {'EWMA': _EWMA})):
+        mod = types.ModuleType(name)
+        mod.__dict__.update(attrs)
+        sys.modules[name] = mod
+    sys.modules['caffe'] = caffe_net
+    sys.path.insert(0, REF)
+
+
+class _SyncQueue:
+    """put() hands the request straight to the worker; get() pops what is stored."""
+
+    def __init__(self, on_put=None):
+        self.items = collections.deque()
+        self.on_put = on_put
+
+    def put(self, item):
+        self.items.append(item)
+        if self.on_put:
+            self.on_put()
+
+    def get(self):
+        return self.items.popleft()
+
+
+def make_sync_pool(st, model_args, n_workers=1, pool_cls=None):
+    """A TileWorkerPool whose workers run the reference's process_one_request in-process."""
+    pool = object.__new__(pool_cls or st.TileWorkerPool)
+    pool.workers, pool.req_count, pool.next_worker, pool.is_healthy = [], 0, 0, True
+    pool.resp_q = _SyncQueue()
+    for _ in range(n_workers):
+        worker = object.__new__(st.TileWorker)
+        worker.resp_q = pool.resp_q
+        worker.model = st.CaffeModel(*model_args)
+        worker.model.img = np.zeros((3, 1, 1), np.float32)
+        worker.proc = types.SimpleNamespace(exitcode=None, terminate=lambda: None)
+        worker.req_q = _SyncQueue(on_put=worker.process_one_request)
+        pool.workers.append(worker)
+    return pool
+
+
+def smooth_image(seed, h, w):
+    """Low-pass filtered seeded noise as a uint8 RGB picture (no photos ship with the reference)."""
+    rng = np.random.RandomState(seed)
+    small = rng.uniform(0, 255, (max(2, h // 8), max(2, w // 8), 3)).astype(np.uint8)
+    img = Image.fromarray(small).resize((w, h), Image.BICUBIC)
+    arr = np.asarray(img).astype(np.float32) + rng.uniform(-20, 20, (h, w, 3))
+    return np.uint8(np.clip(arr, 0, 255))
+
+
+def main():
+    install_stubs()
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png']
+    import config_system
+    import num_utils
+    import optimizers
+    import style_transfer as st
+
+    out = {}
+
+    # ---------------------------------------------------------------- 1. numeric helpers
+    rng = np.random.RandomState(1)
+    feat = np.maximum(rng.standard_normal((64, 17, 23)), 0).astype(np.float32)
+    other = rng.standard_normal((64, 64)).astype(np.float32)
+    gram = num_utils.gram_matrix(feat)
+    symm_in = np.tril(gram - np.tril(other) * 0.01)
+    out['num/feat'] = feat
+    out['num/gram'] = gram
+    out['num/symm_in'] = symm_in
+    out['num/symm_out'] = num_utils.ssymm(symm_in, feat.reshape(64, -1))
+    out['num/norm2'] = np.float64(num_utils.norm2(symm_in))
+    out['num/normalize'] = num_utils.normalize(feat.copy())
+    img = rng.uniform(-120, 130, (3, 21, 34)).astype(np.float32)
+    out['num/img'] = img
+    for beta in (2, 1.5):
+        loss, grad = num_utils.tv_norm(img / 127.5, beta=beta)
+        out['num/tv_loss_%g' % beta] = np.float64(loss)
+        out['num/tv_grad_%g' % beta] = grad
+    loss, grad = num_utils.p_norm(img / 127.5, p=6.0)
+    out['num/p6_loss'], out['num/p6_grad'] = np.float64(loss), grad
+    out['num/roll_3_-5'] = num_utils.roll2(img.copy(), np.array([3, -5]))
+
+    # ------------------------------------------------- 2. tile path over the caffe shim
+    mean = (103.939, 116.779, 123.68)
+    cases = [
+        dict(tag='vgg19', proto='vgg19.prototxt', shapes=st.VGG19_SHAPES, content=(96, 112),
+             styles=[(80, 72)], tile=64, roll=(16, -24)),
+        dict(tag='vgg16avg', proto='vgg16_avgpool.prototxt', shapes=st.VGG16_SHAPES,
+             content=(75, 93), styles=[(66, 59), (50, 71)], tile=48, roll=(-8, 40)),
+    ]
+    for ci, case in enumerate(cases):
+        tag = 'tile/%s/' % case['tag']
+        model_args = (os.path.join(REF, case['proto']), 'synthetic', mean, case['shapes'])
+        st.ARGS = config_system.parse_args(st.STATE)
+        master = st.CaffeModel(*model_args, placeholder=True)
+        pool = make_sync_pool(st, model_args, n_workers=2)
+        content_u8 = smooth_image(10 + ci, *case['content'])
+        style_u8 = [smooth_image(20 + ci * 5 + j, *hw) for j, hw in enumerate(case['styles'])]
+        content_layers, content_weight = st.StyleTransfer.parse_weights(['conv4_2'], 0.05)
+        style_layers, style_weight = st.StyleTransfer.parse_weights(
+            ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1'], 1)
+        np.random.seed(123)
+        master.preprocess_images(pool, [Image.fromarray(content_u8)],
+                                 [Image.fromarray(s) for s in style_u8],
+                                 content_layers, style_layers, case['tile'])
+        pool.set_contents_and_styles(master.contents, master.styles)
+        layer_weights = {layer: 1.0 for layer in master.layers() + ['data']}
+        layer_weights['conv3_1'] = 1.5
+        img = master.pil_to_image(Image.fromarray(smooth_image(30 + ci, *case['content'])))
+        master.img = img.copy()
+        roll = np.array(case['roll'])
+        st.roll2(master.img, roll)
+        loss, grad = master.eval_sc_grad(pool, roll, content_layers, style_layers, [],
+                                         layer_weights, content_weight, style_weight, {},
+                                         case['tile'])
+        out[tag + 'content_u8'] = content_u8
+        for j, s in enumerate(style_u8):
+            out[tag + 'style%d_u8' % j] = s
+        out[tag + 'img_rolled'] = master.img
+        out[tag + 'roll'] = roll
+        out[tag + 'tile_size'] = np.int64(case['tile'])
+        out[tag + 'loss'] = np.float64(loss)
+        out[tag + 'grad'] = grad
+        out[tag + 'lw_conv3_1'] = np.float64(1.5)
+        # spot pins of the targets (full Grams / feature maps are too large to commit)
+        for layer, g in master.styles[0].grams.items():
+            out[tag + 'gram_sum/' + layer] = np.float64(g.sum(dtype=np.float64))
+            out[tag + 'gram_diag8/' + layer] = np.diag(g)[:8].copy()
+        cf = master.contents[0].features['conv4_2']
+        out[tag + 'content_feat_shape'] = np.int64(cf.shape)
+        out[tag + 'content_feat_sum'] = np.float64(cf.sum(dtype=np.float64))
+        out[tag + 'content_feat_c0'] = cf[0].copy()
+
+        # one standalone tile with a non-zero start, straight through eval_sc_grad_tile
+        worker_model = pool.workers[0].model
+        tile = master.img[:, 8:8 + 40, 16:16 + 56].copy()
+        layers = [l for l in reversed(master.layers()) if l in content_layers + style_layers]
+        tloss, tgrad = worker_model.eval_sc_grad_tile(
+            tile, np.array([8, 16]), layers, content_layers, style_layers, [], layer_weights,
+            content_weight, style_weight, {})
+        out[tag + 'single/loss'] = np.float64(tloss)
+        out[tag + 'single/grad'] = tgrad.copy()
+        feats = worker_model.eval_features_tile(tile, ['conv1_1', 'pool1', 'conv5_1'])
+        out[tag + 'single/feat_conv5_1'] = feats['conv5_1'].copy()
+        out[tag + 'single/feat_pool1_sum'] = np.float64(feats['pool1'].sum(dtype=np.float64))
+
+    # ------------------------------------------------------------ 3. optimizer trajectories
+    def quad_opfunc(target):
+        def f(x):
+            d = x - target
+            return float(np.sum(d * d, dtype=np.float64)), (2 * d).astype(np.float32)
+        return f
+
+    rng = np.random.RandomState(7)
+    target = rng.uniform(-100, 100, (3, 12, 20)).astype(np.float32)
+    x0 = rng.uniform(-100, 100, (3, 12, 20)).astype(np.float32)
+    rolls = [(3, -2), (0, 0), (-5, 4), (1, 1), (7, 0)]
+    out['opt/target'], out['opt/x0'], out['opt/rolls'] = target, x0, np.int64(rolls)
+    for biased in (False, True):
+        params = x0.copy()
+        tgt = target.copy()
+        opt = optimizers.AdamOptimizer(params, step_size=15, bp1=1 - 1 / 20, decay=0.05,
+                                       power=0.5, biased_g1=biased)
+        traj, losses = [], []
+        for xy in rolls:
+            xy = np.array(xy)
+            num_utils.roll2(params, xy), num_utils.roll2(tgt, xy)
+            opt.roll(xy)
+            avg, loss = opt.update(quad_opfunc(tgt))
+            num_utils.roll2(params, -xy), num_utils.roll2(tgt, -xy)
+            opt.roll(-xy)
+            traj.append(avg.copy()), losses.append(loss)
+        key = 'opt/adam_biased%d/' % biased
+        out[key + 'avg'], out[key + 'loss'] = np.stack(traj), np.float64(losses)
+        out[key + 'params'] = params.copy()
+    params = x0.copy()
+    tgt = target.copy()
+    scale = np.linspace(0.5, 2, target.size).reshape(target.shape).astype(np.float32)
+
+    def lb_opfunc(x):
+        d = (x - tgt) * scale
+        return float(np.sum(d * d, dtype=np.float64)), (2 * d * scale).astype(np.float32)
+    opt = optimizers.LBFGSOptimizer(params)
+    traj, losses = [], []
+    for _ in range(14):
+        p, loss = opt.update(lb_opfunc)
+        traj.append(p.copy()), losses.append(loss)
+    out['opt/lbfgs/scale'] = scale
+    out['opt/lbfgs/params'], out['opt/lbfgs/loss'] = np.stack(traj), np.float64(losses)
+
+    # --------------------------------------------- 4. the whole multi-scale schedule, tiny
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png', '--size', '96',
+                '--min-size', '60', '--tile-size', '48', '--iterations', '3', '2',
+                '--display', 'none', '--seed', '5']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    model_args = (os.path.join(REF, 'vgg19.prototxt'), 'synthetic', mean, st.VGG19_SHAPES)
+    ref_pool_cls = st.TileWorkerPool
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(40, 96, 80)
+    style_u8 = smooth_image(41, 70, 90)
+    log = []
+
+    class Cb:
+        def set_steps(self, steps):
+            self.steps = steps
+
+        def __call__(self, **kw):
+            log.append((kw['step'], kw['update_size'], kw['loss'], kw['tv_loss']))
+    np.random.seed(st.ARGS.seed)
+    transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                 None, None, callback=Cb())
+    out['e2e/content_u8'], out['e2e/style_u8'] = content_u8, style_u8
+    out['e2e/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e/log'] = np.float64(log)
+    out['e2e/final_raw'] = transfer.current_raw.copy()
+    out['e2e/final_u8'] = np.asarray(transfer.current_output)
+
+    # ------------------------------------------------------------------ 5. parse_args defaults
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png']
+    args = config_system.parse_args(st.STATE)
+    defaults = {k: getattr(args, k) for k in args}
+    out['args/defaults_repr'] = np.array(repr(sorted((k, str(v)) for k, v in defaults.items())))
+
+    path = os.path.join(HERE, 'reference_vectors.npz')
+    np.savez_compressed(path, **{k.replace('/', '.'): v for k, v in out.items()})
+    print('wrote %s (%d arrays, %.1f KiB)' % (path, len(out), os.path.getsize(path) / 1024))
+    num_utils.POOL.shutdown()
+
+
+if __name__ == '__main__':
+    main()

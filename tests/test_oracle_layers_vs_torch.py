@@ -1,0 +1,54 @@
+"""Cross-check of the oracle's Caffe-layer arithmetic against torch-CPU autograd
+(BVLC/caffe itself is un-vendored, so this is the independent pin for conv/pool semantics)."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import layers as L
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(3, 64, 33, 47), (64, 64, 32, 32), (256, 512, 9, 11)])
+def test_conv_fwd_dgrad(cin, cout, h, w):
+    rng = np.random.RandomState(cin + h)
+    x = rng.standard_normal((cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2 / (9 * cin))).astype(np.float32)
+    b = (0.01 * rng.standard_normal(cout)).astype(np.float32)
+    dy = rng.standard_normal((cout, h, w)).astype(np.float32)
+    xt = torch.tensor(x[None], requires_grad=True)
+    yt = F.conv2d(xt, torch.tensor(wt), torch.tensor(b), padding=1)
+    yt.backward(torch.tensor(dy[None]))
+    y = L.conv_forward(x, wt, b)
+    assert np.abs(y - yt[0].detach().numpy()).max() < 2e-4 * np.abs(y).max()
+    dx = L.conv_backward_data(dy, wt)
+    assert np.abs(dx - xt.grad[0].numpy()).max() < 2e-4 * np.abs(dx).max()
+
+
+@pytest.mark.parametrize('h,w', [(8, 8), (7, 9), (1, 5), (33, 2)])
+@pytest.mark.parametrize('mode', ['MAX', 'AVE'])
+def test_pool_ceil_mode(h, w, mode):
+    rng = np.random.RandomState(h * 31 + w)
+    # post-ReLU-like input: many exact zeros, so MAX windows tie often
+    x = np.maximum(rng.standard_normal((5, h, w)), 0).astype(np.float32)
+    x[:, ::3] = 0
+    y, aux = L.pool_forward(x, mode)
+    xt = torch.tensor(x[None], requires_grad=True)
+    if mode == 'MAX':
+        yt = F.max_pool2d(xt, 2, 2, ceil_mode=True)
+    else:
+        yt = F.avg_pool2d(xt, 2, 2, ceil_mode=True, count_include_pad=False)
+    assert y.shape == tuple(yt.shape[1:]) == (5, L.pooled_size(h), L.pooled_size(w))
+    assert np.allclose(y, yt[0].detach().numpy(), atol=1e-6)
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    dx = L.pool_backward(dy, x.shape, aux, mode)
+    if mode == 'AVE':
+        yt.backward(torch.tensor(dy[None]))
+        assert np.allclose(dx, xt.grad[0].numpy(), atol=1e-6)
+    else:
+        # every output's gradient lands on exactly one input of its window, the FIRST maximum
+        assert np.allclose(dx.sum(), dy.sum(), rtol=1e-4)
+        for c, i, j in [(0, 0, 0), (4, y.shape[1] - 1, y.shape[2] - 1), (2, 0, y.shape[2] - 1)]:
+            win = x[c, 2 * i:2 * i + 2, 2 * j:2 * j + 2]
+            k = int(np.argmax(win.ravel()))
+            assert aux[c, i, j] == (k // win.shape[1]) * 2 + (k % win.shape[1])
