@@ -1,0 +1,234 @@
+/*
+ * stx.h -- C ABI of libstx, the MI355X (gfx950) tile engine for tiled neural style transfer.
+ *
+ * This is the drop-in boundary for the hot path of crowsonkb/style_transfer.  The reference has
+ * no native plugin ABI; its hot path sits behind the tile-worker message protocol
+ * (style_transfer.py:156-166), served by TileWorker.process_one_request (style_transfer.py:215-259)
+ * which calls CaffeModel.eval_features_tile / eval_sc_grad_tile (style_transfer.py:421-427,
+ * 556-612), and behind the host-side numpy in eval_loss_and_grad (style_transfer.py:700-736) and
+ * optimizers.py.  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns STX_OK (0) or a negative stx_status; nothing throws or aborts across
+ *     the ABI; stx_last_error() gives the message of the calling thread's last failure;
+ *   - plain pointers and sizes only.  A pointer argument that may live on either side carries an
+ *     stx_mem tag: STX_HOST (pageable or pinned host memory) or STX_DEVICE (memory of the engine's
+ *     GPU, e.g. from stx_malloc or any HIP allocation of this process);
+ *   - buffers are caller-owned; float tensors are dense row-major float32 in the reference's
+ *     layouts: images [3][H][W] (BGR, mean-subtracted), feature maps [C][h][w], Grams [C][C];
+ *   - an engine owns one GPU and one HIP stream.  Calls on one engine are issued in order on that
+ *     stream and are ASYNCHRONOUS w.r.t. the host unless stated; stx_sync() waits and then
+ *     publishes pending scalar results (losses).  Engines on different GPUs are independent --
+ *     that independence is the whole multi-GPU story (tiles never exchange data);
+ *   - one host thread per engine at a time.
+ */
+#ifndef STX_H_
+#define STX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stx_engine stx_engine;
+
+typedef enum stx_status {
+    STX_OK = 0,
+    STX_ERR_ARG = -1,          /* bad argument (null pointer, unknown layer name, bad shape) */
+    STX_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed */
+    STX_ERR_STATE = -3,        /* call sequence error (e.g. weights or targets not set) */
+    STX_ERR_UNSUPPORTED = -4,  /* graph / parameter outside what the kernels implement */
+    STX_ERR_NOMEM = -5
+} stx_status;
+
+typedef enum stx_mem { STX_HOST = 0, STX_DEVICE = 1 } stx_mem;
+
+typedef enum stx_layer_type {
+    STX_LAYER_INPUT = 0, STX_LAYER_CONV = 1, STX_LAYER_RELU = 2, STX_LAYER_POOL = 3
+} stx_layer_type;
+
+typedef enum stx_pool_mode { STX_POOL_MAX = 0, STX_POOL_AVE = 1 } stx_pool_mode;
+
+/* One layer of a Caffe deploy.prototxt (vgg19.prototxt:3-342): same names, same graph. */
+typedef struct stx_layer_desc {
+    const char *name;       /* layer name, e.g. "conv1_1", "relu1_1", "pool1" */
+    int type;               /* stx_layer_type */
+    const char *bottom;     /* input blob name (NULL for the input layer) */
+    const char *top;        /* output blob name; ReLU must be in-place (top == bottom) */
+    int num_output;         /* conv: output channels; input layer: image channels (3) */
+    int kernel_size;        /* conv: 3 (pad 1) or 1 (pad 0); pool: 2 */
+    int pad;                /* conv */
+    int stride;             /* pool: 2 */
+    int pool_mode;          /* stx_pool_mode */
+} stx_layer_desc;
+
+/* ---------------------------------------------------------------- library / device queries */
+const char *stx_version(void);
+/* Message of the calling thread's most recent failing call ("" if none). */
+const char *stx_last_error(void);
+/* Number of visible GPUs; replaces detect_devices() (config_system.py:17-24, nvidia-smi -L). */
+int stx_device_count(int *count);
+/* gcnArchName of a device (e.g. "gfx950:sramecc+:xnack-") into buf. */
+int stx_device_name(int device, char *buf, size_t buf_len);
+
+/* ------------------------------------------------------------------------ engine lifetime */
+/* Replaces TileWorker.run's setup (style_transfer.py:187-207: pick device, caffe.Net(deploy, 1,
+ * weights)).  The graph is copied.  Weights are supplied separately with stx_set_conv_weights. */
+int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, stx_engine **out);
+void stx_engine_destroy(stx_engine *e);
+/* Caffe blob layout: weights [Cout][Cin][k][k], bias [Cout], float32 (Appendix C of SURVEY.md). */
+int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *weights,
+                         const float *bias, int mem);
+/* Waits for all work queued on the engine, then writes pending loss values. */
+int stx_sync(stx_engine *e);
+int stx_engine_device(stx_engine *e, int *device);
+/* The engine's hipStream_t as an opaque pointer (for callers that enqueue their own copies). */
+int stx_engine_stream(stx_engine *e, void **hip_stream);
+
+/* ---------------------------------------------------------------------------- raw memory */
+int stx_malloc(stx_engine *e, size_t bytes, void **dev_ptr);
+int stx_free(stx_engine *e, void *dev_ptr);
+int stx_memset_async(stx_engine *e, void *dev_ptr, int value, size_t bytes);
+/* dst/src tagged with stx_mem; device<->device copies may cross GPUs (xGMI peer copy). */
+int stx_memcpy_async(stx_engine *e, void *dst, int dst_mem, const void *src, int src_mem,
+                     size_t bytes);
+
+/* ------------------------------------------------------------------- targets (per scale) */
+/* One content feature map: ContentData.features[layer] (style_transfer.py:165,246-249), the
+ * FULL-image map [C][h][w] with h = ceil(H/scale), w = ceil(W/scale) (style_transfer.py:440). */
+typedef struct stx_content_target {
+    int content_index;      /* index into model.contents (normally 0) */
+    const char *layer;
+    int channels, height, width;
+    const float *features;
+    int mem;
+} stx_content_target;
+
+/* One style Gram: StyleData.grams[layer] (style_transfer.py:166,250-253), [C][C], only the lower
+ * triangle is read (num_utils.py:53-66). */
+typedef struct stx_style_target {
+    int style_index;        /* index into model.styles (normally 0) */
+    const char *layer;
+    int channels;
+    const float *gram;
+    int mem;
+} stx_style_target;
+
+/* Replaces the SetContentsAndStyles message (style_transfer.py:163,243-254,309-332): replaces all
+ * targets held by the engine.  Data is copied before the call returns control of the buffers
+ * (host sources: synchronously; device sources: ordered on the engine stream). */
+int stx_set_contents_and_styles(stx_engine *e, const stx_content_target *contents, int n_contents,
+                                const stx_style_target *styles, int n_styles);
+
+/* --------------------------------------------------------------------------- the hot path */
+/* Replaces CaffeModel.eval_features_tile via FeatureMapRequest (style_transfer.py:156,221-228,
+ * 421-427): forward the tile and return the post-ReLU maps of the requested blobs.
+ * out[i] receives [C_i][ceil(th/scale_i)][ceil(tw/scale_i)] floats. */
+int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
+                      const char *const *layers, int n_layers, float *const *out, int out_mem);
+
+/* One tapped blob of an SCGradRequest: layer_weights[layer], content_weight[layer] (0 = not a
+ * content layer), style_weight[layer] (0 = not a style layer) -- style_transfer.py:158-161,570,
+ * 579-580,591-593.  Deep-Dream taps (dd_layers) are not implemented (default dd_weight 0). */
+typedef struct stx_tap {
+    const char *layer;
+    double layer_weight;
+    int is_content;
+    double content_weight;
+    int is_style;
+    double style_weight;
+} stx_tap;
+
+/* Replaces the SCGradRequest branch of TileWorker.process_one_request + CaffeModel.
+ * eval_sc_grad_tile (style_transfer.py:230-241,556-612).
+ *   img        [3][th][tw] tile of the (rolled) image;
+ *   roll_xy    the request's roll: the engine addresses its content maps as if rolled by
+ *              roll_xy // scale with numpy.roll(axis=(-1,-2)) semantics, i.e. roll_xy[0] shifts
+ *              the W axis and roll_xy[1] the H axis (num_utils.py:136-140); no copy is made;
+ *   start_yx   tile origin in the rolled image (y, x) (style_transfer.py:571-573);
+ *   loss_out   host double; written by the next stx_sync() (or immediately if sync_now != 0);
+ *   grad_out   [3][th][tw], the reference's diff['data'].
+ */
+int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
+                     const int roll_xy[2], const int start_yx[2], const stx_tap *taps, int n_taps,
+                     double *loss_out, float *grad_out, int grad_mem, int sync_now);
+
+/* Lower-triangular Gram of a feature map, F F^T / (C*h*w), upper triangle zero: gram_matrix
+ * (num_utils.py:143-147) as used for the style targets (style_transfer.py:534). */
+int stx_gram_matrix(stx_engine *e, const float *feat, int feat_mem, int channels, int hw,
+                    float *gram_out, int gram_mem);
+
+/* ------------------------------------------------- full-image ops (device-resident state) */
+/* All pointers in this group are STX_DEVICE memory on the engine's GPU, images are [3][H][W].
+ * The image and the optimizer state are kept UN-rolled; the per-iteration random shift
+ * (style_transfer.py:777-806) is applied as an index offset when tiles are cut and when tile
+ * gradients are put back, which is equivalent to the reference's roll / un-roll pair. */
+
+/* tile[c][y][x] = img[c][(y0 + y - roll_xy[1]) mod H][(x0 + x - roll_xy[0]) mod W]: the window
+ * [y0,y0+th) x [x0,x0+tw) of roll2(img, roll_xy) (style_transfer.py:632,661). */
+int stx_image_cut_tile(stx_engine *e, const float *img, int H, int W, const int roll_xy[2],
+                       int y0, int x0, int th, int tw, float *tile);
+/* Inverse placement of a tile gradient into the un-rolled full gradient
+ * (style_transfer.py:642 followed by the un-roll at 805-806). */
+int stx_image_put_tile(stx_engine *e, float *grad, int H, int W, const int roll_xy[2],
+                       int y0, int x0, int th, int tw, const float *tile_grad);
+
+/* TV + p-norm + auxiliary-image terms of eval_loss_and_grad (style_transfer.py:709-733,
+ * num_utils.py:74-82,150-162): grad += tv_scale*d tv_norm(img/127.5, tv_power)
+ *                                    + p_scale*d p_norm((img+mean-127.5)/127.5, p_power)
+ *                                    + aux_scale*(img-aux)/127.5;
+ * *loss_out (host, written at stx_sync) = tv_scale*TV + p_scale*P + aux_scale*A.
+ * A scale of 0 disables a term; aux may be NULL.  mean_bgr is a host array of 3 floats. */
+int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,
+                           const float mean_bgr[3], double tv_scale, double tv_power,
+                           double p_scale, double p_power, const float *aux, double aux_scale,
+                           double *loss_out);
+
+/* AdamOptimizer.update after the gradient is known (optimizers.py:35-42), fused:
+ *   g1 = b1*g1 + (1-b1)*grad; g2 = b2*g2 + (1-b2)*grad^2; p1 likewise on the new params;
+ *   params -= lr * (g1/c1) / (sqrt(g2/c2) + EPS);  avg_out = p1/cp
+ * where c1, c2, cp are the EWMA bias corrections (1 - beta^t, or 1 when uncorrected). */
+int stx_adam_step(stx_engine *e, float *params, const float *grad, float *g1, float *g2, float *p1,
+                  float *avg_out, size_t n, double lr, double b1, double b2, double bp1,
+                  double corr1, double corr2, double corrp);
+
+/* BLAS-1 pieces of LBFGSOptimizer (optimizers.py:74-121; num_utils.py:20-42). */
+int stx_vec_dot(stx_engine *e, const float *x, const float *y, size_t n, double *out_host_sync);
+int stx_vec_axpy(stx_engine *e, double a, const float *x, float *y, size_t n);
+int stx_vec_scale(stx_engine *e, double a, float *x, size_t n);
+int stx_vec_mean_abs(stx_engine *e, const float *x, size_t n, double *out_host_sync);
+
+/* Per-step statistics of transfer() (style_transfer.py:808-815):
+ * stats[0] = mean|avg - old|, stats[1] = sqrt(mean(xdiff^2 + ydiff^2)) with circular forward
+ * differences; then old <- avg.  Synchronous (returns after the values are on the host). */
+int stx_image_step_stats(stx_engine *e, const float *avg, float *old, int H, int W,
+                         double stats[2]);
+
+/* get_image (style_transfer.py:378-386): out_rgb_u8[H][W][3] = uint8(clip(img + mean, 0, 255))
+ * with BGR->RGB flip and truncation toward zero.  out is STX_DEVICE memory. */
+int stx_image_to_u8(stx_engine *e, const float *img, int H, int W, const float mean_bgr[3],
+                    uint8_t *out_rgb_u8);
+
+/* ------------------------------------------------------------- single-kernel test hooks */
+/* Direct entry points to the individual kernels, used by tests/ to check each against the
+ * oracle (x, w, b, y: STX_DEVICE).  w is the Caffe layout [Cout][Cin][k][k]. */
+int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, const float *w,
+                        const float *b, int Cout, int ksize, int relu, float *y);
+int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, int W,
+                              const float *w, int Cin, int ksize, const float *relu_mask_data,
+                              float *dx);
+int stx_op_pool_forward(stx_engine *e, const float *x, int C, int H, int W, int mode, float *y);
+int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, int H, int W,
+                         int mode, const float *relu_mask_data, float *dx);
+
+/* Timing: ms spent by the GPU between the first and last kernel of the most recent
+ * stx_sc_grad_tile / stx_features_tile on this engine (HIP events on the engine stream);
+ * valid after stx_sync. */
+int stx_last_tile_ms(stx_engine *e, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STX_H_ */

@@ -1,0 +1,150 @@
+// Internal declarations shared by the libstx translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "stx.h"
+
+namespace stx {
+
+// float32 machine epsilon: num_utils.py:14 (EPS), used by normalize / tv_norm / Adam.
+constexpr float kEps = 1.1920928955078125e-07f;
+
+void set_error(const char *fmt, ...);
+
+#define STX_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t err__ = (call);                                                          \
+        if (err__ != hipSuccess) {                                                          \
+            ::stx::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,            \
+                             hipGetErrorString(err__));                                     \
+            return STX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define STX_CHECK_LAUNCH()                                                                  \
+    do {                                                                                    \
+        hipError_t err__ = hipGetLastError();                                               \
+        if (err__ != hipSuccess) {                                                          \
+            ::stx::set_error("%s:%d: kernel launch failed: %s", __FILE__, __LINE__,        \
+                             hipGetErrorString(err__));                                     \
+            return STX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define STX_TRY(expr)                                                                       \
+    do {                                                                                    \
+        int rc__ = (expr);                                                                  \
+        if (rc__ != STX_OK) return rc__;                                                    \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int pooled_len(int n) { return n >= 2 ? (n - 2 + 1) / 2 + 1 : 1; }  // ceil((n-2)/2)+1
+
+// ------------------------------------------------------------------------------------------------
+// Kernel launchers (each enqueues on `stream` and returns STX_OK / STX_ERR_*).
+// ------------------------------------------------------------------------------------------------
+
+// Epilogue selection for the implicit-GEMM MFMA kernel.
+enum ConvEpilogue {
+    kEpiForward = 0,   // y = [relu](acc + bias)
+    kEpiDgrad = 1,     // y = acc * (mask > 0)      (mask optional)
+    kEpiSymm = 2       // y = acc, plus per-workgroup sum|y| partials
+};
+
+struct ConvProblem {
+    const float *x;        // [K][H][W] input planes (activations or upstream gradient)
+    const float *w;        // weight rows, see conv_mfma.hip (packed tiles or a dense symmetric matrix)
+    float *y;              // [M][H][W]
+    const float *bias;     // kEpiForward: [M] or null
+    const float *mask;     // kEpiDgrad: [M][H][W] post-ReLU data of the output blob, or null
+    float *partials;       // kEpiSymm: one float per workgroup
+    int K, M, H, W;        // reduction channels, output channels, plane size
+    int ksize;             // 3 (pad 1) or 1 (pad 0)
+    int relu;              // kEpiForward
+    int epilogue;
+};
+
+// Tile configuration chosen for a problem; weights must be packed for the same (bm, kc).
+struct ConvConfig {
+    int id;        // index into the instantiation table
+    int bm;        // output channels per workgroup
+    int kc;        // reduction channels per LDS stage
+    int pr, pc;    // pixel tile rows x cols
+    int threads;
+    size_t lds_bytes;
+};
+
+ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W);
+int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W);
+// Packed weight buffer size (floats) for a [M][K][ks][ks] filter bank under cfg.
+size_t conv_packed_floats(const ConvConfig &cfg, int K, int M, int ksize);
+// Packs Caffe-layout weights w[Mo][Ko][ks][ks] (device) into the kernel's tile layout.
+// transpose_flip = 0: forward (M = Mo, K = Ko).  1: backward-data (M = Ko, K = Mo, taps rotated 180).
+int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int ksize,
+                      int transpose_flip, const ConvConfig &cfg, float *packed);
+int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
+
+int pool_forward_launch(hipStream_t s, const float *x, int C, int H, int W, int mode, float *y);
+// dx = route(dy) [* (x > 0) when masked]; x is the pool input data (post-ReLU).
+int pool_backward_launch(hipStream_t s, const float *dy, const float *x, int C, int H, int W,
+                         int mode, bool relu_mask, float *dx);
+
+// Gram: partial products over split-K slices, then a fixed-order reduction.
+struct GramPlan {
+    int C, HW, splits, tiles;      // tiles = lower-triangular 64x64 tiles
+    size_t partial_floats;
+};
+GramPlan gram_plan(int C, int HW);
+int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials);
+// gram_out (lower-tri, upper zero) = sum_s partials * 1/(C*HW).  If target != null also writes
+// dsym = sym(tril(gram - target)) and sumsq[0] = sum over the lower triangle of (gram-target)^2.
+int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
+                       const float *target, float *dsym, float *sumsq);
+
+// sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
+// content map.
+struct ContentWindow {
+    int C, fh, fw;          // tile feature size
+    int ch, cw;             // full content map size
+    int oy, ox;             // window origin in the rolled map
+    int sy, sx;             // roll shifts (rows, cols)
+};
+int content_sums_launch(hipStream_t s, const float *feat, const float *content,
+                        const ContentWindow &win, float *sums /*[2]*/);
+// diff (=|+=) coef / (abs_sum/n + EPS) * term, term = S (style) or F - Fc (content).
+int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
+                        const float *abs_sum, const float *partials, int n_partials, float coef,
+                        bool accumulate);
+int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
+                          const ContentWindow &win, const float *sums, float coef, bool accumulate);
+int relu_inplace_launch(hipStream_t s, float *x, size_t n);
+int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
+
+// image_ops.hip
+int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int ry, int y0, int x0,
+                    int th, int tw, float *tile);
+int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, int y0, int x0,
+                    int th, int tw, const float *tile);
+int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
+                        const float mean[3], float tv_scale, float tv_power, float p_scale,
+                        float p_power, const float *aux, float aux_scale, double *loss_terms /*[3]*/,
+                        float *scratch, size_t scratch_floats);
+int adam_launch(hipStream_t s, float *params, const float *grad, float *g1, float *g2, float *p1,
+                float *avg, size_t n, float lr, float b1, float b2, float bp1, float c1, float c2,
+                float cp);
+int dot_launch(hipStream_t s, const float *x, const float *y, size_t n, double *out_dev,
+               float *scratch, size_t scratch_floats);
+int abs_sum_launch(hipStream_t s, const float *x, size_t n, double *out_dev, float *scratch,
+                   size_t scratch_floats);
+int axpy_launch(hipStream_t s, float a, const float *x, float *y, size_t n);
+int scale_launch(hipStream_t s, float a, float *x, size_t n);
+int step_stats_launch(hipStream_t s, const float *avg, float *old, int H, int W,
+                      double *out_dev /*[2]*/, float *scratch, size_t scratch_floats);
+int to_u8_launch(hipStream_t s, const float *img, int H, int W, const float mean[3], uint8_t *out);
+
+}  // namespace stx

@@ -1,0 +1,416 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on the gfx950 fp32 matrix cores.
+//
+// One kernel serves four jobs of the per-tile path (style_transfer.py:556-612 delegates them to
+// Caffe's Convolution layer and to scipy's SSYMM):
+//   * conv forward + bias + ReLU                       (net.forward,  style_transfer.py:425,566)
+//   * conv backward-to-data + ReLU mask of the blob below   (net.backward, style_transfer.py:608-610)
+//     -- the same kernel with the filter bank transposed and rotated by 180 degrees
+//   * S = sym(tril(G - Gs)) . F, the style gradient          (ssymm, num_utils.py:60-66)
+//     -- a 1x1 "convolution" whose weights are the symmetric matrix itself, plus sum|S| partials
+//
+// GEMM view: D[m][p] = sum_k A[m][k] * B[k][p], m = output channel, p = pixel of a PR x PC patch,
+// k = (input channel, tap).  v_mfma_f32_32x32x2_f32 computes a 32(m) x 32(p) block per wave-
+// instruction with K = 2: lanes 0-31 feed k, lanes 32-63 feed k+1 (one VGPR per operand).  With
+// p = 32 consecutive x of one image row, the B operand of tap (ky,kx) is a 32-float run of the
+// LDS-staged input patch shifted by (ky,kx) -- conflict-free ds_read_b32 -- and every D register
+// stores a 128-byte row segment of the NCHW output.  fp32 MFMA issues once per 64 cycles per
+// SIMD, so LDS (two or six ds_read_b32 per eight MFMAs) and the global->LDS stage are far from
+// their limits; the structure is: register-prefetch the next K-chunk from global while the
+// current chunk is multiplied out of LDS, two workgroups per CU to cover the stage swap.
+//
+// Numerics: exact fp32 FMA chains in k order (the MFMA f32 path does not round differently from
+// v_fma_f32), accumulation in fp32 like Caffe's SGEMM.
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace stx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKernelArgs {
+    const float *x;
+    const float *w;
+    float *y;
+    const float *bias;
+    const float *mask;
+    float *partials;
+    int K, M, H, W;
+    int n_chunks;          // ceil(K / KC)
+    int tiles_x, tiles_y;  // pixel tiles
+    int w_row_stride;      // floats between consecutive k rows of the weight source
+    long w_tile_stride;    // floats between consecutive output-channel tiles (packed mode)
+    int relu;
+};
+
+// KS: kernel size (3 -> pad 1, 1 -> pad 0).  KC: reduction channels per stage (even).
+// Wave grid WM x WN, each wave owns TM x TN blocks of 32 channels x 32 pixels.
+// Pixel patch PR rows x PC cols (PC multiple of 32); PR * PC / 32 == TN * WN.
+// PACKED: weights come as pre-tiled [m_tile][k_row][BM] slabs (always in bounds);
+// otherwise as rows of a dense [K][M] matrix (the symmetric style matrix) with bounds masks.
+template <int KS, int KC, int TM, int TN, int WM, int WN, int PR, int PC, int EPI, bool PACKED>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelArgs a) {
+    constexpr int KK = KS * KS;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int XR = PR + KS - 1;
+    constexpr int XC = PC + KS - 1;
+    constexpr int PAD = KS / 2;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int SEGS = PC / 32;
+    static_assert(PR * SEGS == TN * WN, "pixel blocks must match the wave grid");
+    static_assert(KC % 2 == 0, "MFMA consumes k in pairs");
+    constexpr int W_FLOATS = KC * KK * BM;
+    constexpr int X_FLOATS = KC * XR * XC;
+    constexpr int W_VEC4 = W_FLOATS / 4;
+    constexpr int NW = (W_VEC4 + NT - 1) / NT;       // float4 weight loads per thread per stage
+    constexpr int NX = (X_FLOATS + NT - 1) / NT;     // input loads per thread per stage
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Wl = lds;
+    float *Xl = lds + W_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int n_ptiles = a.tiles_x * a.tiles_y;
+    const int ptile = blockIdx.x % n_ptiles;
+    const int mtile = blockIdx.x / n_ptiles;
+    const int y0 = (ptile / a.tiles_x) * PR;
+    const int x0 = (ptile % a.tiles_x) * PC;
+    const int m0 = mtile * BM;
+    const int HW = a.H * a.W;
+
+    const float *wsrc = PACKED ? a.w + (long)mtile * a.w_tile_stride : a.w + m0;
+
+    float4 wreg[NW];
+    float xreg[NX];
+
+    auto load_stage = [&](int chunk) {
+        const int krow0 = chunk * KC * KK;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int f = tid + n * NT;
+            const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+            if (PACKED) {
+                // packed slabs are padded to whole stages: always in bounds
+                const bool ok = NW * NT == W_VEC4 || f < W_VEC4;
+                wreg[n] = *reinterpret_cast<const float4 *>(
+                    wsrc + (ok ? (long)(krow0 + row) * BM + c4 : 0));
+            } else {
+                // dense symmetric matrix: M is a multiple of 4, rows are 16-byte aligned
+                const bool ok = (NW * NT == W_VEC4 || f < W_VEC4) && krow0 + row < a.K &&
+                                m0 + c4 < a.M;
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    ok ? wsrc + (long)(krow0 + row) * a.w_row_stride + c4 : a.w);
+                wreg[n] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const int c0 = chunk * KC;
+        // Branch-free: out-of-range elements (zero padding at the tile border, channel padding)
+        // read element 0 and are zeroed by a select, so all NX loads are issued back to back.
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + n * NT;
+            const int ci = e / (XR * XC);
+            const int rem = e - ci * (XR * XC);
+            const int r = rem / XC, c = rem - r * XC;
+            const int yy = y0 - PAD + r, xx = x0 - PAD + c;
+            const bool ok = (NX * NT == X_FLOATS || e < X_FLOATS) && c0 + ci < a.K &&
+                            (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const int off = ok ? (c0 + ci) * HW + yy * a.W + xx : 0;
+            const float v = a.x[off];
+            xreg[n] = ok ? v : 0.f;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int f = tid + n * NT;
+            if (NW * NT == W_VEC4 || f < W_VEC4) reinterpret_cast<float4 *>(Wl)[f] = wreg[n];
+        }
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + n * NT;
+            if (NX * NT == X_FLOATS || e < X_FLOATS) Xl[e] = xreg[n];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-wave operand bases (lanes 32..63 read the odd k of each pair)
+    const float *wl = Wl + half * (KK * BM) + wm * (TM * 32) + l31;
+    int xoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pb = wn * TN + j;
+        xoff[j] = half * (XR * XC) + (pb / SEGS) * XC + (pb % SEGS) * 32 + l31;
+    }
+
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+        const bool more = chunk + 1 < a.n_chunks;
+        if (more) load_stage(chunk + 1);
+#pragma unroll
+        for (int q = 0; q < KC / 2; ++q) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int ky = t / KS, kx = t % KS;
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = wl[((2 * q) * KK + t) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bv[j] = Xl[(2 * q) * (XR * XC) + ky * XC + kx + xoff[j]];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j],
+                                                                         0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D register r of a block holds row (r&3) + 8*(r>>2) + 4*half, column l31.
+    float abs_sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pb = wn * TN + j;
+        const int yy = y0 + pb / SEGS;
+        const int xx = x0 + (pb % SEGS) * 32 + l31;
+        const bool in_img = yy < a.H && xx < a.W;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (in_img && m < a.M) {
+                    const long idx = (long)m * HW + yy * a.W + xx;
+                    float v = acc[i][j][r];
+                    if (EPI == kEpiForward) {
+                        if (a.bias) v += a.bias[m];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                    } else if (EPI == kEpiDgrad) {
+                        if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                    } else {
+                        abs_sum += fabsf(v);
+                    }
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+    if (EPI == kEpiSymm) {
+        // workgroup reduction of sum|S| -> one partial per workgroup (summed later in fixed order)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) abs_sum += __shfl_down(abs_sum, off, 64);
+        __syncthreads();
+        if (lane == 0) lds[wave] = abs_sum;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int i = 0; i < WM * WN; ++i) s += lds[i];
+            a.partials[blockIdx.x] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Instantiation table
+// ------------------------------------------------------------------------------------------------
+struct ConvVariant {
+    int ks, kc, tm, tn, wm, wn, pr, pc;
+};
+
+static const ConvVariant kVariants[] = {
+    /*0*/ {3, 8, 2, 4, 2, 2, 8, 32},   // BM 128 x 256 px : wide middle layers
+    /*1*/ {3, 4, 2, 4, 1, 4, 8, 64},   // BM  64 x 512 px : 64-channel layers at full resolution
+    /*2*/ {3, 8, 2, 2, 1, 4, 8, 32},   // BM  64 x 256 px : deep layers with few pixels
+    /*3*/ {3, 8, 1, 2, 1, 4, 8, 32},   // BM  32 x 256 px : backward into the 3-channel image
+    /*4*/ {3, 4, 2, 4, 1, 4, 8, 64},   // BM  64 x 512 px, KC 4 : first layer (3 input channels)
+    /*5*/ {3, 8, 2, 1, 1, 4, 4, 32},   // BM  64 x 128 px : smallest planes
+    /*6*/ {1, 16, 2, 4, 2, 2, 8, 32},  // 1x1, BM 128 : style-gradient product, C >= 128
+    /*7*/ {1, 16, 2, 4, 1, 4, 8, 64},  // 1x1, BM  64 : style-gradient product, C == 64
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+static ConvConfig make_config(int id) {
+    const ConvVariant &v = kVariants[id];
+    ConvConfig c;
+    c.id = id;
+    c.bm = 32 * v.tm * v.wm;
+    c.kc = v.kc;
+    c.pr = v.pr;
+    c.pc = v.pc;
+    c.threads = 64 * v.wm * v.wn;
+    const int kk = v.ks * v.ks;
+    c.lds_bytes = sizeof(float) * ((size_t)v.kc * kk * c.bm +
+                                   (size_t)v.kc * (v.pr + v.ks - 1) * (v.pc + v.ks - 1));
+    return c;
+}
+
+int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W) {
+    return ceil_div(M, cfg.bm) * ceil_div(H, cfg.pr) * ceil_div(W, cfg.pc);
+}
+
+ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
+    if (ksize == 1) return make_config(M >= 128 ? 6 : 7);
+    if (K <= 4) return make_config(4);
+    if (M <= 32) return make_config(3);
+    // prefer the largest tile that still gives every CU two workgroups (256 CUs)
+    const int order_wide[] = {0, 2, 5};
+    const int order_64[] = {1, 2, 5};
+    const int *order = M <= 64 ? order_64 : order_wide;
+    for (int i = 0; i < 3; ++i) {
+        ConvConfig c = make_config(order[i]);
+        if (conv_num_workgroups(c, M, H, W) >= 512 || i == 2) return c;
+    }
+    return make_config(5);
+}
+
+size_t conv_packed_floats(const ConvConfig &cfg, int K, int M, int ksize) {
+    const size_t kpad = (size_t)ceil_div(K, cfg.kc) * cfg.kc;
+    return (size_t)ceil_div(M, cfg.bm) * kpad * ksize * ksize * cfg.bm;
+}
+
+// packed[mt][(k*KK + t)][mm] = W(m = mt*BM + mm, k, t), zero outside the filter bank.
+__global__ void pack_weights_kernel(const float *__restrict__ w, int Mo, int Ko, int ks,
+                                    int transpose_flip, int M, int K, int bm, int kpad,
+                                    float *__restrict__ packed, size_t total) {
+    const int kk = ks * ks;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int mm = i % bm;
+        const size_t row = i / bm;
+        const int t = row % kk;
+        const int k = (row / kk) % kpad;
+        const int mt = row / ((size_t)kk * kpad);
+        const int m = mt * bm + mm;
+        float v = 0.f;
+        if (m < M && k < K) {
+            if (!transpose_flip)
+                v = w[((size_t)m * Ko + k) * kk + t];
+            else  // backward-data: out channel m is the filter's input channel, taps rotated 180
+                v = w[((size_t)k * Ko + m) * kk + (kk - 1 - t)];
+        }
+        packed[i] = v;
+    }
+}
+
+int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int ksize,
+                      int transpose_flip, const ConvConfig &cfg, float *packed) {
+    const int M = transpose_flip ? Ko : Mo;
+    const int K = transpose_flip ? Mo : Ko;
+    const int kpad = ceil_div(K, cfg.kc) * cfg.kc;
+    const size_t total = conv_packed_floats(cfg, K, M, ksize);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    pack_weights_kernel<<<blocks, 256, 0, s>>>(w_caffe, Mo, Ko, ksize, transpose_flip, M, K, cfg.bm,
+                                               kpad, packed, total);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+#define STX_CONV_VARIANT(ID, KS, KC, TM, TN, WM, WN, PR, PC)                                      \
+    template <int EPI, bool PACKED>                                                               \
+    static int launch_##ID(hipStream_t s, const ConvConfig &cfg, const ConvKernelArgs &args,      \
+                           int n_wg) {                                                            \
+        auto kern = conv_mfma_kernel<KS, KC, TM, TN, WM, WN, PR, PC, EPI, PACKED>;                \
+        if (cfg.lds_bytes > 64 * 1024) {                                                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),              \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               (int)cfg.lds_bytes);                               \
+            if (e != hipSuccess) {                                                                \
+                set_error("hipFuncSetAttribute(lds=%zu): %s", cfg.lds_bytes,                      \
+                          hipGetErrorString(e));                                                  \
+                return STX_ERR_HIP;                                                               \
+            }                                                                                     \
+        }                                                                                         \
+        kern<<<n_wg, cfg.threads, cfg.lds_bytes, s>>>(args);                                      \
+        STX_CHECK_LAUNCH();                                                                       \
+        return STX_OK;                                                                            \
+    }
+
+STX_CONV_VARIANT(0, 3, 8, 2, 4, 2, 2, 8, 32)
+STX_CONV_VARIANT(1, 3, 4, 2, 4, 1, 4, 8, 64)
+STX_CONV_VARIANT(2, 3, 8, 2, 2, 1, 4, 8, 32)
+STX_CONV_VARIANT(3, 3, 8, 1, 2, 1, 4, 8, 32)
+STX_CONV_VARIANT(4, 3, 4, 2, 4, 1, 4, 8, 64)
+STX_CONV_VARIANT(5, 3, 8, 2, 1, 1, 4, 4, 32)
+STX_CONV_VARIANT(6, 1, 16, 2, 4, 2, 2, 8, 32)
+STX_CONV_VARIANT(7, 1, 16, 2, 4, 1, 4, 8, 64)
+
+int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed) {
+    const ConvVariant &v = kVariants[cfg.id];
+    if (v.ks != p.ksize) {
+        set_error("conv_launch: config %d is %dx%d, problem is %dx%d", cfg.id, v.ks, v.ks, p.ksize,
+                  p.ksize);
+        return STX_ERR_ARG;
+    }
+    ConvKernelArgs a;
+    a.x = p.x;
+    a.w = p.w;
+    a.y = p.y;
+    a.bias = p.bias;
+    a.mask = p.mask;
+    a.partials = p.partials;
+    a.K = p.K;
+    a.M = p.M;
+    a.H = p.H;
+    a.W = p.W;
+    a.n_chunks = ceil_div(p.K, cfg.kc);
+    a.tiles_x = ceil_div(p.W, cfg.pc);
+    a.tiles_y = ceil_div(p.H, cfg.pr);
+    a.w_row_stride = packed ? cfg.bm : p.M;
+    a.w_tile_stride = packed ? (long)a.n_chunks * cfg.kc * p.ksize * p.ksize * cfg.bm : 0;
+    a.relu = p.relu;
+    const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
+
+#define STX_DISPATCH(ID)                                                                          \
+    case ID:                                                                                      \
+        if (p.epilogue == kEpiForward && packed)                                                  \
+            return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
+        if (p.epilogue == kEpiDgrad && packed) return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg); \
+        break;
+#define STX_DISPATCH_SYMM(ID)                                                                     \
+    case ID:                                                                                      \
+        if (p.epilogue == kEpiSymm && !packed) return launch_##ID<kEpiSymm, false>(s, cfg, a, n_wg); \
+        if (p.epilogue == kEpiForward && packed)                                                  \
+            return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
+        if (p.epilogue == kEpiDgrad && packed) return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg); \
+        break;
+    switch (cfg.id) {
+        STX_DISPATCH(0)
+        STX_DISPATCH(1)
+        STX_DISPATCH(2)
+        STX_DISPATCH(3)
+        STX_DISPATCH(4)
+        STX_DISPATCH(5)
+        STX_DISPATCH_SYMM(6)
+        STX_DISPATCH_SYMM(7)
+    }
+#undef STX_DISPATCH
+#undef STX_DISPATCH_SYMM
+    set_error("conv_launch: no kernel for config %d epilogue %d packed %d", cfg.id, p.epilogue,
+              (int)packed);
+    return STX_ERR_UNSUPPORTED;
+}
+
+}  // namespace stx

@@ -1,0 +1,1090 @@
+// libstx host side: the tile engine behind include/stx.h.
+//
+// One engine = one GPU + one HIP stream + one copy of the network (graph, weights packed for the
+// MFMA kernels) + the current targets (content feature maps, style Grams).  It plays the role of
+// the reference's TileWorker process (style_transfer.py:169-259) with CaffeModel.eval_features_tile
+// / eval_sc_grad_tile (style_transfer.py:421-427,556-612) inside, but is driven by plain function
+// calls that enqueue kernels asynchronously instead of pickled messages over multiprocessing
+// queues and POSIX shared memory.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace stx {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+// Growable device buffer.  Growth frees and reallocates (hipFree synchronises the device, so
+// kernels still reading the old allocation have finished); it happens only when a larger tile
+// than ever before arrives.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return STX_OK;
+        if (ptr) STX_HIP(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+        const size_t want = (need + 255) & ~(size_t)255;
+        hipError_t err = hipMalloc(&ptr, want);
+        if (err != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(err));
+            ptr = nullptr;
+            return STX_ERR_NOMEM;
+        }
+        bytes = want;
+        return STX_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    float *f() const { return static_cast<float *>(ptr); }
+};
+
+struct Layer {
+    std::string name, bottom, top;
+    int type = 0, num_output = 0, ksize = 0, pad = 0, stride = 1, pool_mode = 0;
+    int bottom_blob = -1, top_blob = -1;
+};
+
+struct Blob {
+    std::string name;
+    int channels = 0;
+    int producer = -1;   // layer index that writes it (conv / pool / input)
+    bool relu = false;   // an in-place ReLU layer follows the producer
+    int scale = 1;       // 224 // height at a 224 input (CaffeModel.layer_info, style_transfer.py:415-419)
+    int h = 0, w = 0;    // current tile
+    DevBuf data, diff;
+    size_t count() const { return (size_t)channels * h * w; }
+};
+
+struct ConvParams {
+    int cin = 0, cout = 0, ks = 0;
+    DevBuf w, b;                              // Caffe layout on the device
+    bool set = false;
+    std::map<int, std::unique_ptr<DevBuf>> packed;  // key = dir * 64 + config id
+};
+
+struct ContentTarget {
+    int index, blob, C, h, w;
+    std::unique_ptr<DevBuf> feat;
+};
+
+struct StyleTarget {
+    int index, blob, C;
+    std::unique_ptr<DevBuf> gram;
+};
+
+struct LossTerm {
+    size_t scalar_index;   // float in the host mirror of the scalar buffer
+    double coef;
+};
+
+struct PendingLoss {
+    double *out;
+    std::vector<LossTerm> terms;       // sum coef * scalar
+    std::vector<LossTerm> dterms;      // sum coef * double scalar (image ops)
+};
+
+}  // namespace stx
+
+using namespace stx;
+
+struct stx_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::vector<Layer> layers;
+    std::vector<Blob> blobs;
+    std::map<std::string, int> blob_index, layer_index;
+    std::map<int, ConvParams> conv;   // layer index -> params
+    std::vector<ContentTarget> contents;
+    std::vector<StyleTarget> styles;
+    int n_contents = 0, n_styles = 0;
+
+    DevBuf sgrad, gram_partials, gram, dsym, symm_partials, upload, img_scratch;
+    DevBuf scalars;                    // device floats
+    float *scalars_host = nullptr;     // pinned mirror
+    size_t scalars_cap = 0, scalars_used = 0;
+    DevBuf dscalars;                   // device doubles (image-op reductions)
+    double *dscalars_host = nullptr;
+    size_t dscalars_cap = 64, dscalars_used = 0;
+    DevBuf red_scratch;                // float partials for image-op reductions
+    std::vector<PendingLoss> pending;
+
+    int set_device() {
+        STX_HIP(hipSetDevice(device));
+        return STX_OK;
+    }
+    int find_blob(const char *name) const {
+        if (!name) return -1;
+        auto it = blob_index.find(name);
+        return it == blob_index.end() ? -1 : it->second;
+    }
+};
+
+namespace {
+
+constexpr size_t kScalarFloats = 1 << 16;   // per-call scalar arena (sums + small partials)
+
+int alloc_scalars(stx_engine *e, size_t n, size_t *index) {
+    if (e->scalars_used + n > e->scalars_cap) {
+        set_error("scalar arena exhausted (%zu + %zu > %zu)", e->scalars_used, n, e->scalars_cap);
+        return STX_ERR_NOMEM;
+    }
+    *index = e->scalars_used;
+    e->scalars_used += n;
+    return STX_OK;
+}
+
+int alloc_dscalars(stx_engine *e, size_t n, size_t *index) {
+    if (e->dscalars_used + n > e->dscalars_cap - 4) {   // the last slots serve synchronous results
+        // no wrap: results are consumed at every stx_sync, which also resets the arena
+        set_error("double-scalar arena exhausted; call stx_sync more often");
+        return STX_ERR_NOMEM;
+    }
+    *index = e->dscalars_used;
+    e->dscalars_used += n;
+    return STX_OK;
+}
+
+// Copies caller memory (host or device) into a device destination on the engine stream.
+int copy_in(stx_engine *e, void *dst, const void *src, int mem, size_t bytes) {
+    if (mem == STX_HOST)
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    else
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, e->stream));
+    return STX_OK;
+}
+
+int copy_out(stx_engine *e, void *dst, int mem, const void *src, size_t bytes) {
+    if (mem == STX_HOST)
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    else
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, e->stream));
+    return STX_OK;
+}
+
+// Sets blob shapes for a th x tw tile and makes sure data buffers exist for `needed` blobs.
+int shape_blobs(stx_engine *e, int th, int tw, const std::vector<char> &needed, bool with_diff) {
+    Blob &in = e->blobs[e->layers[0].top_blob];
+    in.h = th;
+    in.w = tw;
+    for (size_t li = 1; li < e->layers.size(); ++li) {
+        const Layer &L = e->layers[li];
+        if (L.type == STX_LAYER_RELU) continue;
+        const Blob &b = e->blobs[L.bottom_blob];
+        Blob &t = e->blobs[L.top_blob];
+        if (L.type == STX_LAYER_CONV) {
+            t.h = b.h;
+            t.w = b.w;
+        } else {
+            t.h = pooled_len(b.h);
+            t.w = pooled_len(b.w);
+        }
+    }
+    for (size_t bi = 0; bi < e->blobs.size(); ++bi) {
+        if (!needed[bi]) continue;
+        Blob &b = e->blobs[bi];
+        STX_TRY(b.data.ensure(b.count() * sizeof(float)));
+        if (with_diff) STX_TRY(b.diff.ensure(b.count() * sizeof(float)));
+    }
+    return STX_OK;
+}
+
+// Marks `blob` and everything it depends on.
+void mark_ancestors(const stx_engine *e, int blob, std::vector<char> &needed) {
+    while (blob >= 0 && !needed[blob]) {
+        needed[blob] = 1;
+        const int p = e->blobs[blob].producer;
+        if (p <= 0) break;
+        blob = e->layers[p].bottom_blob;
+    }
+}
+
+int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const float **out) {
+    ConvParams &cp = e->conv[layer];
+    if (!cp.set) {
+        set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
+        return STX_ERR_STATE;
+    }
+    const int key = dir * 64 + cfg.id;
+    auto it = cp.packed.find(key);
+    if (it == cp.packed.end()) {
+        const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
+        std::unique_ptr<DevBuf> buf(new DevBuf);
+        STX_TRY(buf->ensure(conv_packed_floats(cfg, K, M, cp.ks) * sizeof(float)));
+        STX_TRY(conv_pack_weights(e->stream, cp.w.f(), cp.cout, cp.cin, cp.ks, dir, cfg, buf->f()));
+        it = cp.packed.emplace(key, std::move(buf)).first;
+    }
+    *out = it->second->f();
+    return STX_OK;
+}
+
+int run_conv_forward(stx_engine *e, int li, bool force_relu) {
+    const Layer &L = e->layers[li];
+    const Blob &b = e->blobs[L.bottom_blob];
+    Blob &t = e->blobs[L.top_blob];
+    const ConvParams &cp = e->conv[li];
+    const ConvConfig cfg = conv_pick_config(cp.ks, cp.cin, cp.cout, b.h, b.w);
+    const float *packed = nullptr;
+    STX_TRY(get_packed(e, li, 0, cfg, &packed));
+    ConvProblem p{};
+    p.x = b.data.f();
+    p.w = packed;
+    p.y = t.data.f();
+    p.bias = cp.b.f();
+    p.K = cp.cin;
+    p.M = cp.cout;
+    p.H = b.h;
+    p.W = b.w;
+    p.ksize = cp.ks;
+    p.relu = (t.relu || force_relu) ? 1 : 0;
+    p.epilogue = kEpiForward;
+    return conv_launch(e->stream, cfg, p, true);
+}
+
+int run_conv_backward(stx_engine *e, int li) {
+    const Layer &L = e->layers[li];
+    Blob &b = e->blobs[L.bottom_blob];
+    const Blob &t = e->blobs[L.top_blob];
+    const ConvParams &cp = e->conv[li];
+    const ConvConfig cfg = conv_pick_config(cp.ks, cp.cout, cp.cin, b.h, b.w);
+    const float *packed = nullptr;
+    STX_TRY(get_packed(e, li, 1, cfg, &packed));
+    ConvProblem p{};
+    p.x = t.diff.f();
+    p.w = packed;
+    p.y = b.diff.f();
+    p.mask = b.relu ? b.data.f() : nullptr;
+    p.K = cp.cout;
+    p.M = cp.cin;
+    p.H = b.h;
+    p.W = b.w;
+    p.ksize = cp.ks;
+    p.epilogue = kEpiDgrad;
+    return conv_launch(e->stream, cfg, p, true);
+}
+
+// Runs the layers needed for `needed` blobs, in graph order.  `relu_blob` (or -1) is rectified
+// even when no ReLU layer follows it (np.maximum(0, .) at style_transfer.py:426,567).
+int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
+    for (size_t li = 1; li < e->layers.size(); ++li) {
+        const Layer &L = e->layers[li];
+        if (L.type == STX_LAYER_RELU || !needed[L.top_blob]) continue;
+        const Blob &b = e->blobs[L.bottom_blob];
+        Blob &t = e->blobs[L.top_blob];
+        if (L.type == STX_LAYER_CONV) {
+            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob));
+        } else {
+            STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
+                                        t.data.f()));
+            if (t.relu || L.top_blob == relu_blob)
+                STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
+        }
+    }
+    return STX_OK;
+}
+
+int begin_timing(stx_engine *e) {
+    STX_HIP(hipEventRecord(e->ev_start, e->stream));
+    return STX_OK;
+}
+
+int end_timing(stx_engine *e) {
+    STX_HIP(hipEventRecord(e->ev_stop, e->stream));
+    e->timed = true;
+    return STX_OK;
+}
+
+int publish_pending(stx_engine *e) {
+    for (const PendingLoss &pl : e->pending) {
+        double v = 0.0;
+        for (const LossTerm &t : pl.terms) v += t.coef * (double)e->scalars_host[t.scalar_index];
+        for (const LossTerm &t : pl.dterms) v += t.coef * e->dscalars_host[t.scalar_index];
+        if (pl.out) *pl.out = v;
+    }
+    e->pending.clear();
+    e->scalars_used = 0;
+    e->dscalars_used = 0;
+    return STX_OK;
+}
+
+int do_sync(stx_engine *e) {
+    STX_HIP(hipStreamSynchronize(e->stream));
+    return publish_pending(e);
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char *stx_version(void) { return "libstx 0.1 (gfx950)"; }
+
+const char *stx_last_error(void) { return g_error.c_str(); }
+
+int stx_device_count(int *count) {
+    if (!count) return STX_ERR_ARG;
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return STX_OK;
+}
+
+int stx_device_name(int device, char *buf, size_t buf_len) {
+    if (!buf || !buf_len) return STX_ERR_ARG;
+    hipDeviceProp_t prop;
+    STX_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s", prop.gcnArchName);
+    return STX_OK;
+}
+
+int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, stx_engine **out) {
+    if (!layers || n_layers < 2 || !out) {
+        set_error("stx_engine_create: bad arguments");
+        return STX_ERR_ARG;
+    }
+    if (layers[0].type != STX_LAYER_INPUT || !layers[0].top) {
+        set_error("stx_engine_create: layer 0 must be the input layer");
+        return STX_ERR_ARG;
+    }
+    std::unique_ptr<stx_engine> e(new stx_engine);
+    e->device = device;
+    hipError_t err = hipSetDevice(device);
+    if (err != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", device, hipGetErrorString(err));
+        return STX_ERR_HIP;
+    }
+    auto add_blob = [&](const std::string &name, int channels, int producer) {
+        Blob b;
+        b.name = name;
+        b.channels = channels;
+        b.producer = producer;
+        e->blob_index[name] = (int)e->blobs.size();
+        e->blobs.push_back(std::move(b));
+        return (int)e->blobs.size() - 1;
+    };
+    for (int i = 0; i < n_layers; ++i) {
+        const stx_layer_desc &d = layers[i];
+        Layer L;
+        L.name = d.name ? d.name : "";
+        L.bottom = d.bottom ? d.bottom : "";
+        L.top = d.top ? d.top : "";
+        L.type = d.type;
+        L.num_output = d.num_output;
+        L.ksize = d.kernel_size;
+        L.pad = d.pad;
+        L.stride = d.stride;
+        L.pool_mode = d.pool_mode;
+        if (L.top.empty()) {
+            set_error("layer %d (%s) has no top blob", i, L.name.c_str());
+            return STX_ERR_ARG;
+        }
+        if (i == 0) {
+            L.top_blob = add_blob(L.top, d.num_output > 0 ? d.num_output : 3, 0);
+        } else {
+            auto it = e->blob_index.find(L.bottom);
+            if (it == e->blob_index.end()) {
+                set_error("layer %s: unknown bottom blob '%s'", L.name.c_str(), L.bottom.c_str());
+                return STX_ERR_ARG;
+            }
+            L.bottom_blob = it->second;
+            if (L.type == STX_LAYER_RELU) {
+                if (L.top != L.bottom) {
+                    set_error("layer %s: only in-place ReLU is supported", L.name.c_str());
+                    return STX_ERR_UNSUPPORTED;
+                }
+                L.top_blob = L.bottom_blob;
+                e->blobs[L.top_blob].relu = true;
+            } else if (L.type == STX_LAYER_CONV) {
+                if (!((L.ksize == 3 && L.pad == 1) || (L.ksize == 1 && L.pad == 0))) {
+                    set_error("layer %s: only 3x3/pad 1 and 1x1/pad 0 convolutions are supported",
+                              L.name.c_str());
+                    return STX_ERR_UNSUPPORTED;
+                }
+                if (e->blob_index.count(L.top)) {
+                    set_error("layer %s: top blob '%s' already exists", L.name.c_str(), L.top.c_str());
+                    return STX_ERR_UNSUPPORTED;
+                }
+                L.top_blob = add_blob(L.top, L.num_output, i);
+                ConvParams &cp = e->conv[i];
+                cp.cin = e->blobs[L.bottom_blob].channels;
+                cp.cout = L.num_output;
+                cp.ks = L.ksize;
+            } else if (L.type == STX_LAYER_POOL) {
+                if (L.ksize != 2 || L.stride != 2 ||
+                    (L.pool_mode != STX_POOL_MAX && L.pool_mode != STX_POOL_AVE)) {
+                    set_error("layer %s: only 2x2 stride-2 MAX/AVE pooling is supported",
+                              L.name.c_str());
+                    return STX_ERR_UNSUPPORTED;
+                }
+                if (e->blob_index.count(L.top)) {
+                    set_error("layer %s: top blob '%s' already exists", L.name.c_str(), L.top.c_str());
+                    return STX_ERR_UNSUPPORTED;
+                }
+                L.top_blob = add_blob(L.top, e->blobs[L.bottom_blob].channels, i);
+            } else {
+                set_error("layer %s: unsupported type %d", L.name.c_str(), L.type);
+                return STX_ERR_UNSUPPORTED;
+            }
+        }
+        e->layer_index[L.name] = i;
+        e->layers.push_back(std::move(L));
+    }
+    // scale of every blob: 224 // (blob height for a 224 x 224 input)
+    {
+        std::vector<int> h224(e->blobs.size(), 224);
+        for (size_t li = 1; li < e->layers.size(); ++li) {
+            const Layer &L = e->layers[li];
+            if (L.type == STX_LAYER_CONV) h224[L.top_blob] = h224[L.bottom_blob];
+            if (L.type == STX_LAYER_POOL) h224[L.top_blob] = pooled_len(h224[L.bottom_blob]);
+        }
+        for (size_t bi = 0; bi < e->blobs.size(); ++bi) e->blobs[bi].scale = 224 / h224[bi];
+    }
+    STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    STX_HIP(hipEventCreate(&e->ev_start));
+    STX_HIP(hipEventCreate(&e->ev_stop));
+    e->scalars_cap = kScalarFloats;
+    STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
+    STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
+                          e->scalars_cap * sizeof(float), hipHostMallocDefault));
+    STX_TRY(e->dscalars.ensure(e->dscalars_cap * sizeof(double)));
+    STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->dscalars_host),
+                          e->dscalars_cap * sizeof(double), hipHostMallocDefault));
+    STX_TRY(e->red_scratch.ensure(4 * 1024 * sizeof(float)));
+    *out = e.release();
+    return STX_OK;
+}
+
+void stx_engine_destroy(stx_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (Blob &b : e->blobs) {
+        b.data.release();
+        b.diff.release();
+    }
+    for (auto &kv : e->conv) {
+        kv.second.w.release();
+        kv.second.b.release();
+        for (auto &p : kv.second.packed) p.second->release();
+    }
+    for (auto &c : e->contents) c.feat->release();
+    for (auto &s : e->styles) s.gram->release();
+    DevBuf *bufs[] = {&e->sgrad, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
+                      &e->upload, &e->img_scratch, &e->scalars, &e->dscalars, &e->red_scratch};
+    for (DevBuf *b : bufs) b->release();
+    if (e->scalars_host) (void)hipHostFree(e->scalars_host);
+    if (e->dscalars_host) (void)hipHostFree(e->dscalars_host);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *weights,
+                         const float *bias, int mem) {
+    if (!e || !conv_layer || !weights) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    auto it = e->layer_index.find(conv_layer);
+    if (it == e->layer_index.end() || e->layers[it->second].type != STX_LAYER_CONV) {
+        set_error("stx_set_conv_weights: '%s' is not a convolution layer", conv_layer);
+        return STX_ERR_ARG;
+    }
+    ConvParams &cp = e->conv[it->second];
+    const size_t nw = (size_t)cp.cout * cp.cin * cp.ks * cp.ks;
+    STX_TRY(cp.w.ensure(nw * sizeof(float)));
+    STX_TRY(cp.b.ensure((size_t)cp.cout * sizeof(float)));
+    STX_TRY(copy_in(e, cp.w.ptr, weights, mem, nw * sizeof(float)));
+    if (bias)
+        STX_TRY(copy_in(e, cp.b.ptr, bias, mem, (size_t)cp.cout * sizeof(float)));
+    else
+        STX_HIP(hipMemsetAsync(cp.b.ptr, 0, (size_t)cp.cout * sizeof(float), e->stream));
+    // host buffers may be reused by the caller right away
+    if (mem == STX_HOST) STX_HIP(hipStreamSynchronize(e->stream));
+    for (auto &p : cp.packed) p.second->release();
+    cp.packed.clear();
+    cp.set = true;
+    return STX_OK;
+}
+
+int stx_sync(stx_engine *e) {
+    if (!e) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return do_sync(e);
+}
+
+int stx_engine_device(stx_engine *e, int *device) {
+    if (!e || !device) return STX_ERR_ARG;
+    *device = e->device;
+    return STX_OK;
+}
+
+int stx_engine_stream(stx_engine *e, void **hip_stream) {
+    if (!e || !hip_stream) return STX_ERR_ARG;
+    *hip_stream = e->stream;
+    return STX_OK;
+}
+
+int stx_malloc(stx_engine *e, size_t bytes, void **dev_ptr) {
+    if (!e || !dev_ptr) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    hipError_t err = hipMalloc(dev_ptr, bytes ? bytes : 4);
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(err));
+        return STX_ERR_NOMEM;
+    }
+    return STX_OK;
+}
+
+int stx_free(stx_engine *e, void *dev_ptr) {
+    if (!e) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    if (dev_ptr) STX_HIP(hipFree(dev_ptr));
+    return STX_OK;
+}
+
+int stx_memset_async(stx_engine *e, void *dev_ptr, int value, size_t bytes) {
+    if (!e || !dev_ptr) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    STX_HIP(hipMemsetAsync(dev_ptr, value, bytes, e->stream));
+    return STX_OK;
+}
+
+int stx_memcpy_async(stx_engine *e, void *dst, int dst_mem, const void *src, int src_mem,
+                     size_t bytes) {
+    if (!e || !dst || !src) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    hipMemcpyKind kind = hipMemcpyDefault;
+    if (dst_mem == STX_HOST && src_mem == STX_HOST) kind = hipMemcpyHostToHost;
+    if (dst_mem == STX_HOST && src_mem == STX_DEVICE) kind = hipMemcpyDeviceToHost;
+    if (dst_mem == STX_DEVICE && src_mem == STX_HOST) kind = hipMemcpyHostToDevice;
+    STX_HIP(hipMemcpyAsync(dst, src, bytes, kind, e->stream));
+    return STX_OK;
+}
+
+int stx_set_contents_and_styles(stx_engine *e, const stx_content_target *contents, int n_contents,
+                                const stx_style_target *styles, int n_styles) {
+    if (!e || (n_contents && !contents) || (n_styles && !styles)) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    // the previous targets may still be in use by queued kernels
+    STX_HIP(hipStreamSynchronize(e->stream));
+    for (auto &c : e->contents) c.feat->release();
+    for (auto &s : e->styles) s.gram->release();
+    e->contents.clear();
+    e->styles.clear();
+    e->n_contents = e->n_styles = 0;
+    bool host_src = false;
+    for (int i = 0; i < n_contents; ++i) {
+        const stx_content_target &c = contents[i];
+        const int blob = e->find_blob(c.layer);
+        if (blob < 0 || !c.features || c.channels != e->blobs[blob].channels || c.height <= 0 ||
+            c.width <= 0 || c.content_index < 0) {
+            set_error("content target %d: bad layer '%s' or shape", i, c.layer ? c.layer : "(null)");
+            return STX_ERR_ARG;
+        }
+        ContentTarget t;
+        t.index = c.content_index;
+        t.blob = blob;
+        t.C = c.channels;
+        t.h = c.height;
+        t.w = c.width;
+        t.feat.reset(new DevBuf);
+        const size_t bytes = (size_t)t.C * t.h * t.w * sizeof(float);
+        STX_TRY(t.feat->ensure(bytes));
+        STX_TRY(copy_in(e, t.feat->ptr, c.features, c.mem, bytes));
+        host_src |= c.mem == STX_HOST;
+        e->n_contents = std::max(e->n_contents, t.index + 1);
+        e->contents.push_back(std::move(t));
+    }
+    for (int i = 0; i < n_styles; ++i) {
+        const stx_style_target &s = styles[i];
+        const int blob = e->find_blob(s.layer);
+        if (blob < 0 || !s.gram || s.channels != e->blobs[blob].channels || s.style_index < 0) {
+            set_error("style target %d: bad layer '%s' or shape", i, s.layer ? s.layer : "(null)");
+            return STX_ERR_ARG;
+        }
+        StyleTarget t;
+        t.index = s.style_index;
+        t.blob = blob;
+        t.C = s.channels;
+        t.gram.reset(new DevBuf);
+        const size_t bytes = (size_t)t.C * t.C * sizeof(float);
+        STX_TRY(t.gram->ensure(bytes));
+        STX_TRY(copy_in(e, t.gram->ptr, s.gram, s.mem, bytes));
+        host_src |= s.mem == STX_HOST;
+        e->n_styles = std::max(e->n_styles, t.index + 1);
+        e->styles.push_back(std::move(t));
+    }
+    if (host_src) STX_HIP(hipStreamSynchronize(e->stream));
+    return STX_OK;
+}
+
+int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
+                      const char *const *layers, int n_layers, float *const *out, int out_mem) {
+    if (!e || !img || th <= 0 || tw <= 0 || n_layers <= 0 || !layers || !out) {
+        set_error("stx_features_tile: bad arguments");
+        return STX_ERR_ARG;
+    }
+    STX_TRY(e->set_device());
+    std::vector<char> needed(e->blobs.size(), 0);
+    std::vector<int> want(n_layers);
+    for (int i = 0; i < n_layers; ++i) {
+        want[i] = e->find_blob(layers[i]);
+        if (want[i] < 0 || !out[i]) {
+            set_error("stx_features_tile: unknown layer '%s'", layers[i] ? layers[i] : "(null)");
+            return STX_ERR_ARG;
+        }
+        mark_ancestors(e, want[i], needed);
+    }
+    STX_TRY(shape_blobs(e, th, tw, needed, false));
+    Blob &in = e->blobs[e->layers[0].top_blob];
+    STX_TRY(copy_in(e, in.data.ptr, img, img_mem, in.count() * sizeof(float)));
+    STX_TRY(begin_timing(e));
+    // the reference rectifies the net's last blob (style_transfer.py:426)
+    const int last_blob = (int)e->blobs.size() - 1;
+    STX_TRY(forward(e, needed, needed[last_blob] ? last_blob : -1));
+    STX_TRY(end_timing(e));
+    for (int i = 0; i < n_layers; ++i) {
+        const Blob &b = e->blobs[want[i]];
+        STX_TRY(copy_out(e, out[i], out_mem, b.data.ptr, b.count() * sizeof(float)));
+    }
+    return STX_OK;
+}
+
+int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
+                     const int roll_xy[2], const int start_yx[2], const stx_tap *taps, int n_taps,
+                     double *loss_out, float *grad_out, int grad_mem, int sync_now) {
+    if (!e || !img || th <= 0 || tw <= 0 || !taps || n_taps <= 0 || !grad_out || !start_yx) {
+        set_error("stx_sc_grad_tile: bad arguments");
+        return STX_ERR_ARG;
+    }
+    STX_TRY(e->set_device());
+    const int rx = roll_xy ? roll_xy[0] : 0, ry = roll_xy ? roll_xy[1] : 0;
+
+    // ---- taps in deep -> shallow order (style_transfer.py:231-233)
+    struct Tap {
+        int blob;
+        const stx_tap *t;
+    };
+    std::vector<Tap> order;
+    for (int i = 0; i < n_taps; ++i) {
+        const int blob = e->find_blob(taps[i].layer);
+        if (blob <= 0) {
+            set_error("stx_sc_grad_tile: unknown tap layer '%s'",
+                      taps[i].layer ? taps[i].layer : "(null)");
+            return STX_ERR_ARG;
+        }
+        for (const Tap &o : order)
+            if (o.blob == blob) {
+                set_error("stx_sc_grad_tile: layer '%s' is tapped twice", taps[i].layer);
+                return STX_ERR_ARG;
+            }
+        if (!taps[i].is_content && !taps[i].is_style) continue;
+        order.push_back(Tap{blob, &taps[i]});
+    }
+    if (order.empty()) {
+        set_error("stx_sc_grad_tile: no content or style layer");
+        return STX_ERR_ARG;
+    }
+    std::sort(order.begin(), order.end(), [](const Tap &a, const Tap &b) { return a.blob > b.blob; });
+    std::vector<char> needed(e->blobs.size(), 0);
+    mark_ancestors(e, order[0].blob, needed);
+    std::vector<int> tap_of(e->blobs.size(), -1);
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (!needed[order[i].blob]) {
+            set_error("stx_sc_grad_tile: tapped layers must lie on one path through the network "
+                      "('%s' does not feed '%s')", e->blobs[order[i].blob].name.c_str(),
+                      e->blobs[order[0].blob].name.c_str());
+            return STX_ERR_UNSUPPORTED;
+        }
+        tap_of[order[i].blob] = (int)i;
+    }
+    for (const Tap &tp : order) {
+        if (tp.t->is_content && e->n_contents == 0) {
+            set_error("stx_sc_grad_tile: no content targets set");
+            return STX_ERR_STATE;
+        }
+        if (tp.t->is_style && e->n_styles == 0) {
+            set_error("stx_sc_grad_tile: no style targets set");
+            return STX_ERR_STATE;
+        }
+    }
+
+    STX_TRY(shape_blobs(e, th, tw, needed, true));
+    const int data_blob = e->layers[0].top_blob;
+    Blob &in = e->blobs[data_blob];
+    STX_TRY(copy_in(e, in.data.ptr, img, img_mem, in.count() * sizeof(float)));
+    STX_TRY(begin_timing(e));
+    STX_TRY(forward(e, needed, order[0].blob));
+
+    PendingLoss pl;
+    pl.out = loss_out;
+
+    // ---- injection of the loss gradients of one tapped blob into its diff
+    auto inject = [&](const Tap &tp, bool &diff_written) -> int {
+        Blob &b = e->blobs[tp.blob];
+        const double lw = tp.t->layer_weight;
+        if (tp.t->is_content) {
+            bool any = false;
+            for (const ContentTarget &ct : e->contents) {
+                if (ct.blob != tp.blob) continue;
+                any = true;
+                ContentWindow win;
+                win.C = b.channels;
+                win.fh = b.h;
+                win.fw = b.w;
+                win.ch = ct.h;
+                win.cw = ct.w;
+                // start_ = start // scale (style_transfer.py:572); roll // scale per layer (:647-655)
+                win.oy = (int)std::floor((double)start_yx[0] / b.scale);
+                win.ox = (int)std::floor((double)start_yx[1] / b.scale);
+                win.sx = (int)std::floor((double)rx / b.scale);
+                win.sy = (int)std::floor((double)ry / b.scale);
+                if (win.oy + win.fh > win.ch || win.ox + win.fw > win.cw) {
+                    set_error("content window [%d+%d, %d+%d] exceeds the %dx%d map of layer %s",
+                              win.oy, win.fh, win.ox, win.fw, win.ch, win.cw, b.name.c_str());
+                    return STX_ERR_ARG;
+                }
+                size_t si;
+                STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
+                float *sums = e->scalars.f() + si;
+                STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
+                pl.terms.push_back(LossTerm{si, lw * tp.t->content_weight * 0.5});
+                STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), ct.feat->f(), win,
+                                              sums, (float)(lw * tp.t->content_weight),
+                                              diff_written));
+                diff_written = true;
+            }
+            if (!any) {
+                set_error("no content target for layer %s", b.name.c_str());
+                return STX_ERR_STATE;
+            }
+        }
+        if (tp.t->is_style) {
+            bool any = false;
+            for (const StyleTarget &st : e->styles) {
+                if (st.blob != tp.blob) continue;
+                any = true;
+                const int C = b.channels, HW = b.h * b.w;
+                if (C % 4 != 0) {
+                    set_error("style layer %s: channel count %d is not a multiple of 4", b.name.c_str(),
+                              C);
+                    return STX_ERR_UNSUPPORTED;
+                }
+                const GramPlan plan = gram_plan(C, HW);
+                const size_t fin_blocks = ceil_div(C * C, 256);
+                STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
+                STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
+                STX_TRY(e->sgrad.ensure(b.count() * sizeof(float)));
+                size_t si;
+                STX_TRY(alloc_scalars(e, 2, &si));
+                float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
+                STX_TRY(gram_partials_launch(e->stream, b.data.f(), plan, e->gram_partials.f()));
+                STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr,
+                                           st.gram->f(), e->dsym.f(), sc));
+                // S = sym(tril(G - Gs)) . F  with sum|S| partials
+                const ConvConfig cfg = conv_pick_config(1, C, C, b.h, b.w);
+                const int n_wg = conv_num_workgroups(cfg, C, b.h, b.w);
+                STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+                ConvProblem p{};
+                p.x = b.data.f();
+                p.w = e->dsym.f();
+                p.y = e->sgrad.f();
+                p.partials = e->symm_partials.f();
+                p.K = C;
+                p.M = C;
+                p.H = b.h;
+                p.W = b.w;
+                p.ksize = 1;
+                p.epilogue = kEpiSymm;
+                STX_TRY(conv_launch(e->stream, cfg, p, false));
+                STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+                pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->n_styles});
+                STX_TRY(inject_style_launch(e->stream, b.diff.f(), e->sgrad.f(), b.count(), sc + 1,
+                                            nullptr, 0,
+                                            (float)(lw * tp.t->style_weight / e->n_styles),
+                                            diff_written));
+                diff_written = true;
+            }
+            if (!any) {
+                set_error("no style target for layer %s", b.name.c_str());
+                return STX_ERR_STATE;
+            }
+        }
+        return STX_OK;
+    };
+
+    // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
+    int cur = order[0].blob;
+    {
+        bool written = false;
+        STX_TRY(inject(order[0], written));
+        if (!written)
+            STX_HIP(hipMemsetAsync(e->blobs[cur].diff.ptr, 0, e->blobs[cur].count() * sizeof(float),
+                                   e->stream));
+    }
+    while (cur != data_blob) {
+        const int li = e->blobs[cur].producer;
+        const Layer &L = e->layers[li];
+        Blob &bot = e->blobs[L.bottom_blob];
+        const Blob &top = e->blobs[cur];
+        if (L.type == STX_LAYER_CONV) {
+            STX_TRY(run_conv_backward(e, li));
+        } else {
+            STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels, bot.h,
+                                         bot.w, L.pool_mode, bot.relu, bot.diff.f()));
+        }
+        cur = L.bottom_blob;
+        if (tap_of[cur] >= 0) {
+            bool written = true;   // the upstream gradient is already in diff
+            STX_TRY(inject(order[tap_of[cur]], written));
+        }
+    }
+    STX_TRY(end_timing(e));
+    STX_TRY(copy_out(e, grad_out, grad_mem, in.diff.ptr, in.count() * sizeof(float)));
+    // mirror the scalars used so far (small) for the loss
+    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
+                           hipMemcpyDeviceToHost, e->stream));
+    e->pending.push_back(std::move(pl));
+    if (sync_now) return do_sync(e);
+    return STX_OK;
+}
+
+int stx_gram_matrix(stx_engine *e, const float *feat, int feat_mem, int channels, int hw,
+                    float *gram_out, int gram_mem) {
+    if (!e || !feat || !gram_out || channels <= 0 || hw <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const float *src = feat;
+    if (feat_mem == STX_HOST) {
+        STX_TRY(e->upload.ensure((size_t)channels * hw * sizeof(float)));
+        STX_TRY(copy_in(e, e->upload.ptr, feat, STX_HOST, (size_t)channels * hw * sizeof(float)));
+        src = e->upload.f();
+    }
+    const GramPlan plan = gram_plan(channels, hw);
+    STX_TRY(e->gram_partials.ensure(plan.partial_floats * sizeof(float)));
+    STX_TRY(e->gram.ensure((size_t)channels * channels * sizeof(float)));
+    STX_TRY(gram_partials_launch(e->stream, src, plan, e->gram_partials.f()));
+    STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, e->gram.f(), nullptr, nullptr,
+                               nullptr));
+    STX_TRY(copy_out(e, gram_out, gram_mem, e->gram.ptr, (size_t)channels * channels * sizeof(float)));
+    if (feat_mem == STX_HOST || gram_mem == STX_HOST) STX_HIP(hipStreamSynchronize(e->stream));
+    return STX_OK;
+}
+
+// ------------------------------------------------------------------------------- image ops
+int stx_image_cut_tile(stx_engine *e, const float *img, int H, int W, const int roll_xy[2], int y0,
+                       int x0, int th, int tw, float *tile) {
+    if (!e || !img || !tile || H <= 0 || W <= 0 || th <= 0 || tw <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return cut_tile_launch(e->stream, img, H, W, roll_xy ? roll_xy[0] : 0, roll_xy ? roll_xy[1] : 0,
+                           y0, x0, th, tw, tile);
+}
+
+int stx_image_put_tile(stx_engine *e, float *grad, int H, int W, const int roll_xy[2], int y0,
+                       int x0, int th, int tw, const float *tile_grad) {
+    if (!e || !grad || !tile_grad || H <= 0 || W <= 0 || th <= 0 || tw <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return put_tile_launch(e->stream, grad, H, W, roll_xy ? roll_xy[0] : 0,
+                           roll_xy ? roll_xy[1] : 0, y0, x0, th, tw, tile_grad);
+}
+
+int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,
+                           const float mean_bgr[3], double tv_scale, double tv_power, double p_scale,
+                           double p_power, const float *aux, double aux_scale, double *loss_out) {
+    if (!e || !img || !grad || !mean_bgr || H <= 0 || W <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    size_t di;
+    STX_TRY(alloc_dscalars(e, 3, &di));
+    double *terms = static_cast<double *>(e->dscalars.ptr) + di;
+    STX_TRY(regularizers_launch(e->stream, img, grad, H, W, mean_bgr, (float)tv_scale,
+                                (float)tv_power, (float)p_scale, (float)p_power, aux,
+                                (float)aux_scale, terms, e->red_scratch.f(),
+                                e->red_scratch.bytes / sizeof(float)));
+    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, terms, 3 * sizeof(double), hipMemcpyDeviceToHost,
+                           e->stream));
+    PendingLoss pl;
+    pl.out = loss_out;
+    pl.dterms.push_back(LossTerm{di + 0, tv_scale});
+    pl.dterms.push_back(LossTerm{di + 1, p_scale});
+    pl.dterms.push_back(LossTerm{di + 2, aux ? aux_scale * 0.5 : 0.0});
+    e->pending.push_back(std::move(pl));
+    return STX_OK;
+}
+
+int stx_adam_step(stx_engine *e, float *params, const float *grad, float *g1, float *g2, float *p1,
+                  float *avg_out, size_t n, double lr, double b1, double b2, double bp1, double corr1,
+                  double corr2, double corrp) {
+    if (!e || !params || !grad || !g1 || !g2 || !p1 || !avg_out) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return adam_launch(e->stream, params, grad, g1, g2, p1, avg_out, n, (float)lr, (float)b1,
+                       (float)b2, (float)bp1, (float)corr1, (float)corr2, (float)corrp);
+}
+
+static int sync_scalar(stx_engine *e, size_t di, int n, double *out) {
+    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, static_cast<double *>(e->dscalars.ptr) + di,
+                           n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    STX_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n; ++i) out[i] = e->dscalars_host[di + i];
+    return STX_OK;
+}
+
+int stx_vec_dot(stx_engine *e, const float *x, const float *y, size_t n, double *out) {
+    if (!e || !x || !y || !out) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const size_t di = e->dscalars_cap - 2;   // reserved slot for synchronous scalar results
+    STX_TRY(dot_launch(e->stream, x, y, n, static_cast<double *>(e->dscalars.ptr) + di,
+                       e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
+    return sync_scalar(e, di, 1, out);
+}
+
+int stx_vec_mean_abs(stx_engine *e, const float *x, size_t n, double *out) {
+    if (!e || !x || !out || !n) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const size_t di = e->dscalars_cap - 2;
+    STX_TRY(abs_sum_launch(e->stream, x, n, static_cast<double *>(e->dscalars.ptr) + di,
+                           e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
+    STX_TRY(sync_scalar(e, di, 1, out));
+    *out /= (double)n;
+    return STX_OK;
+}
+
+int stx_vec_axpy(stx_engine *e, double a, const float *x, float *y, size_t n) {
+    if (!e || !x || !y) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return axpy_launch(e->stream, (float)a, x, y, n);
+}
+
+int stx_vec_scale(stx_engine *e, double a, float *x, size_t n) {
+    if (!e || !x) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return scale_launch(e->stream, (float)a, x, n);
+}
+
+int stx_image_step_stats(stx_engine *e, const float *avg, float *old, int H, int W, double stats[2]) {
+    if (!e || !avg || !old || !stats || H <= 0 || W <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const size_t di = e->dscalars_cap - 2;
+    STX_TRY(step_stats_launch(e->stream, avg, old, H, W, static_cast<double *>(e->dscalars.ptr) + di,
+                              e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
+    double raw[2];
+    STX_TRY(sync_scalar(e, di, 2, raw));
+    const double n = 3.0 * H * W;
+    stats[0] = raw[0] / n;
+    stats[1] = std::sqrt(raw[1] / n);
+    return STX_OK;
+}
+
+int stx_image_to_u8(stx_engine *e, const float *img, int H, int W, const float mean_bgr[3],
+                    uint8_t *out_rgb_u8) {
+    if (!e || !img || !mean_bgr || !out_rgb_u8 || H <= 0 || W <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return to_u8_launch(e->stream, img, H, W, mean_bgr, out_rgb_u8);
+}
+
+// --------------------------------------------------------------------------- test hooks
+static int scratch_pack(stx_engine *e, const float *w, int Mo, int Ko, int ks, int dir,
+                        const ConvConfig &cfg, const float **packed) {
+    const int M = dir ? Ko : Mo, K = dir ? Mo : Ko;
+    STX_TRY(e->upload.ensure(conv_packed_floats(cfg, K, M, ks) * sizeof(float)));
+    STX_TRY(conv_pack_weights(e->stream, w, Mo, Ko, ks, dir, cfg, e->upload.f()));
+    *packed = e->upload.f();
+    return STX_OK;
+}
+
+int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, const float *w,
+                        const float *b, int Cout, int ksize, int relu, float *y) {
+    if (!e || !x || !w || !y) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const ConvConfig cfg = conv_pick_config(ksize, Cin, Cout, H, W);
+    const float *packed = nullptr;
+    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 0, cfg, &packed));
+    ConvProblem p{};
+    p.x = x;
+    p.w = packed;
+    p.y = y;
+    p.bias = b;
+    p.K = Cin;
+    p.M = Cout;
+    p.H = H;
+    p.W = W;
+    p.ksize = ksize;
+    p.relu = relu;
+    p.epilogue = kEpiForward;
+    return conv_launch(e->stream, cfg, p, true);
+}
+
+int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, int W, const float *w,
+                              int Cin, int ksize, const float *relu_mask_data, float *dx) {
+    if (!e || !dy || !w || !dx) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const ConvConfig cfg = conv_pick_config(ksize, Cout, Cin, H, W);
+    const float *packed = nullptr;
+    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 1, cfg, &packed));
+    ConvProblem p{};
+    p.x = dy;
+    p.w = packed;
+    p.y = dx;
+    p.mask = relu_mask_data;
+    p.K = Cout;
+    p.M = Cin;
+    p.H = H;
+    p.W = W;
+    p.ksize = ksize;
+    p.epilogue = kEpiDgrad;
+    return conv_launch(e->stream, cfg, p, true);
+}
+
+int stx_op_pool_forward(stx_engine *e, const float *x, int C, int H, int W, int mode, float *y) {
+    if (!e || !x || !y) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return pool_forward_launch(e->stream, x, C, H, W, mode, y);
+}
+
+int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, int H, int W,
+                         int mode, const float *relu_mask_data, float *dx) {
+    if (!e || !dy || !x || !dx) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    // the mask source is the pool input itself (post-ReLU data of the blob below)
+    return pool_backward_launch(e->stream, dy, x, C, H, W, mode, relu_mask_data != nullptr, dx);
+}
+
+int stx_last_tile_ms(stx_engine *e, float *ms) {
+    if (!e || !ms) return STX_ERR_ARG;
+    if (!e->timed) {
+        set_error("stx_last_tile_ms: no tile has been evaluated");
+        return STX_ERR_STATE;
+    }
+    STX_TRY(e->set_device());
+    STX_HIP(hipEventSynchronize(e->ev_stop));
+    STX_HIP(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return STX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// Gram matrix G = F F^T / (C*h*w) of a feature map F = [C][h*w] on the fp32 matrix cores.
+//
+// Replaces gram_matrix / ssyrk (num_utils.py:53-56,143-147; callers style_transfer.py:534,584).
+// The reference's SYRK fills only the lower triangle and leaves the upper triangle zero, and
+// every consumer (norm2 of the difference, ssymm) reads just that triangle, so only the
+// lower-triangular 64x64 tiles are computed.  The reduction dimension is the pixel index
+// (up to 2^20 for a 1024x1024 tile at conv1_1) while the output is at most 512x512, so the work is
+// split along K over many workgroups; each writes a 64x64 partial and a second kernel adds the
+// partials in a fixed order (deterministic, no atomics), applies the 1/(C*h*w) scale, subtracts
+// the style target and emits what the rest of the tile path needs:
+//   gram  (lower triangle, upper zero)                          -- style_transfer.py:584
+//   dsym  = sym(tril(gram - target)), the SSYMM left operand    -- style_transfer.py:587-589
+//   sum of squares of tril(gram - target), for the style loss   -- style_transfer.py:591
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32): A[i][k] = F[ci][p], B[k][j] = F[cj][p]; both operands
+// are channel-major in memory, so the LDS tiles are [64 channels][KP pixels + 1 pad] and the
+// 32 lanes of an operand read walk the channel axis with an odd stride (conflict-free).
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace stx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGT = 64;        // tile edge (channels)
+constexpr int kGP = 64;        // pixels per LDS stage
+constexpr int kGLd = kGP + 1;  // padded LDS row
+
+GramPlan gram_plan(int C, int HW) {
+    GramPlan p;
+    p.C = C;
+    p.HW = HW;
+    const int T = ceil_div(C, kGT);
+    p.tiles = T * (T + 1) / 2;
+    int splits = std::max(1, 1024 / p.tiles);
+    splits = std::min(splits, ceil_div(HW, 4 * kGP));   // at least four stages per slice
+    splits = std::max(splits, 1);
+    p.splits = splits;
+    p.partial_floats = (size_t)p.splits * p.tiles * kGT * kGT;
+    return p;
+}
+
+__device__ __forceinline__ void tile_coords(int tile, int &ti, int &tj) {
+    // tile index -> (ti >= tj) in row-major lower-triangular order
+    int r = (int)((sqrtf(8.f * tile + 1.f) - 1.f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+    while (r * (r + 1) / 2 > tile) --r;
+    ti = r;
+    tj = tile - r * (r + 1) / 2;
+}
+
+__global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__restrict__ F, int C,
+                                                              int HW, int tiles, int slice,
+                                                              float *__restrict__ partials) {
+    __shared__ float At[kGT * kGLd];
+    __shared__ float Bt[kGT * kGLd];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    int ti, tj;
+    tile_coords(tile, ti, tj);
+    const bool diag = ti == tj;
+    const int p_begin = split * slice;
+    const int p_end = min(HW, p_begin + slice);
+    const int bi = wave >> 1, bj = wave & 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // each thread stages 16 floats of the A tile and 16 of the B tile per stage:
+    // element e = tid + 256*n -> channel e / 64, pixel e % 64 (coalesced along pixels)
+    float ra[16], rb[16];
+    auto load = [&](int p0) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int e = tid + 256 * n;
+            const int ch = e >> 6, px = p0 + (e & 63);
+            const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+            const bool okp = px < p_end;
+            const bool oka = okp && ca < C, okb = okp && cb < C && !diag;
+            const float va = F[oka ? (size_t)ca * HW + px : 0];
+            const float vb = F[okb ? (size_t)cb * HW + px : 0];
+            ra[n] = oka ? va : 0.f;
+            rb[n] = okb ? vb : 0.f;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int e = tid + 256 * n;
+            const int ch = e >> 6, px = e & 63;
+            At[ch * kGLd + px] = ra[n];
+            if (!diag) Bt[ch * kGLd + px] = rb[n];
+        }
+    };
+
+    const float *ap = At + (bi * 32 + l31) * kGLd + half;
+    const float *bp = (diag ? At : Bt) + (bj * 32 + l31) * kGLd + half;
+
+    if (p_begin < p_end) {
+        load(p_begin);
+        store();
+        __syncthreads();
+        for (int p0 = p_begin; p0 < p_end; p0 += kGP) {
+            const bool more = p0 + kGP < p_end;
+            if (more) load(p0 + kGP);
+#pragma unroll
+            for (int k = 0; k < kGP; k += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
+            __syncthreads();
+            if (more) {
+                store();
+                __syncthreads();
+            }
+        }
+    }
+    float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[i * kGT + bj * 32 + l31] = acc[r];
+    }
+}
+
+int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials) {
+    int slice = ceil_div(plan.HW, plan.splits);
+    slice = ceil_div(slice, kGP) * kGP;
+    gram_partial_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(feat, plan.C, plan.HW, plan.tiles,
+                                                                  slice, partials);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// One thread per (i, j) of the full C x C matrix.
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restrict__ partials, int C,
+                                                          int tiles, int splits, float scale,
+                                                          float *__restrict__ gram,
+                                                          const float *__restrict__ target,
+                                                          float *__restrict__ dsym,
+                                                          float *__restrict__ block_sumsq) {
+    __shared__ float red[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.f;
+    if (idx < C * C) {
+        const int i = idx / C, j = idx % C;
+        const int lo = min(i, j), hi = max(i, j);      // element (hi, lo) of the lower triangle
+        const int ti = hi / kGT, tj = lo / kGT;
+        const int tile = ti * (ti + 1) / 2 + tj;
+        const float *p = partials + (size_t)tile * (kGT * kGT) + (hi % kGT) * kGT + (lo % kGT);
+        float sum = 0.f;
+        for (int s = 0; s < splits; ++s) sum += p[(size_t)s * tiles * (kGT * kGT)];
+        const float g = sum * scale;
+        if (gram) gram[idx] = i >= j ? g : 0.f;
+        if (target) {
+            const float d = g - target[hi * C + lo];
+            dsym[idx] = d;
+            if (i >= j) sq = d * d;
+        }
+    }
+    if (block_sumsq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) block_sumsq[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+__global__ void sum_partials_kernel(const float *__restrict__ partials, int n,
+                                    float *__restrict__ out) {
+    // single workgroup, fixed summation order: thread-strided sums, then a tree over 256 lanes
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out) {
+    sum_partials_kernel<<<1, 256, 0, s>>>(partials, n, out);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
+                       const float *target, float *dsym, float *sumsq) {
+    const int blocks = ceil_div(plan.C * plan.C, 256);
+    // block partial sums live behind the Gram partials (the caller sizes the buffer for both)
+    float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
+    const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
+    gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits, scale,
+                                              gram_out, target, dsym, block_sumsq);
+    STX_CHECK_LAUNCH();
+    if (target) STX_TRY(sum_partials_launch(s, block_sumsq, blocks, sumsq));
+    return STX_OK;
+}
+
+}  // namespace stx

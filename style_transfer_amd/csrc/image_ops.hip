@@ -1,0 +1,342 @@
+// Full-image kernels: tile cut / put with the seam-suppression shift as an index offset, the
+// TV / p-norm / auxiliary regularizers, the fused Adam step, the BLAS-1 pieces of L-BFGS, the
+// per-step statistics and the float -> uint8 conversion.  All are single-pass and HBM-bound;
+// reductions produce per-workgroup partials that a second tiny kernel adds in a fixed order.
+//
+// Reference: style_transfer.py:700-736 (eval_loss_and_grad), 777-815 (roll, statistics),
+// 378-386 (get_image); num_utils.py:74-82 (p_norm), 136-140 (roll2), 150-162 (tv_norm);
+// optimizers.py:26-42 (Adam), 74-121 (L-BFGS vector algebra).
+// This file is compiled with -ffp-contract=off so that elementwise float32 arithmetic rounds
+// like the reference's numpy expressions (one rounding per operation).
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace stx {
+
+constexpr int kBlocks = 1024;   // upper bound on reduction workgroups (scratch is sized for it)
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block-reduces up to NV values and writes partials[v * gridDim.x + blockIdx.x].
+template <int NV>
+__device__ __forceinline__ void block_partials(float (&v)[NV], float *partials) {
+    __shared__ float red[NV][4];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float s = wave_sum_f(v[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            partials[k * gridDim.x + blockIdx.x] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+    }
+}
+
+// out[k] = sum over n partials of value k, accumulated in double in a fixed order.
+template <int NV>
+__global__ void finish_partials_kernel(const float *__restrict__ partials, int n,
+                                       double *__restrict__ out) {
+    __shared__ double red[256];
+    for (int k = 0; k < NV; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[k * n + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = red[0];
+        __syncthreads();
+    }
+}
+
+static int blocks_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, kBlocks); }
+
+// ------------------------------------------------------------------------------ cut / put ---
+__device__ __forceinline__ int wrap(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+template <bool PUT>
+__global__ __launch_bounds__(256) void tile_move_kernel(float *__restrict__ full, int H, int W,
+                                                        int rx, int ry, int y0, int x0, int th,
+                                                        int tw, float *__restrict__ tile) {
+    const size_t total = (size_t)3 * th * tw;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % tw;
+        const int y = (i / tw) % th;
+        const int c = i / ((size_t)tw * th);
+        const size_t j = ((size_t)c * H + wrap(y0 + y - ry, H)) * W + wrap(x0 + x - rx, W);
+        if (PUT)
+            full[j] = tile[i];
+        else
+            tile[i] = full[j];
+    }
+}
+
+int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int ry, int y0, int x0,
+                    int th, int tw, float *tile) {
+    const size_t total = (size_t)3 * th * tw;
+    tile_move_kernel<false><<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
+        const_cast<float *>(img), H, W, rx, ry, y0, x0, th, tw, tile);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, int y0, int x0,
+                    int th, int tw, const float *tile) {
+    const size_t total = (size_t)3 * th * tw;
+    tile_move_kernel<true><<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
+        grad, H, W, rx, ry, y0, x0, th, tw, const_cast<float *>(tile));
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// --------------------------------------------------------------------------- regularizers ---
+struct RegArgs {
+    const float *img;
+    float *grad;
+    const float *aux;
+    int H, W;
+    float mean[3];
+    float tv_scale, tv_half_beta, p_scale, p_power, aux_scale;
+};
+
+__global__ __launch_bounds__(256) void regularizers_kernel(RegArgs a, float *__restrict__ partials) {
+    const size_t plane = (size_t)a.H * a.W, total = 3 * plane;
+    float sums[3] = {0.f, 0.f, 0.f};   // TV, P, AUX (unscaled)
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % a.W;
+        const int y = (i / a.W) % a.H;
+        const int c = i / plane;
+        const float *p = a.img + (size_t)c * plane;
+        const float v = p[(size_t)y * a.W + x];
+        float g = a.grad[i];   // each term is added like a separate saxpy (style_transfer.py:713-733)
+        if (a.tv_scale != 0.f) {
+            const int xp = x + 1 == a.W ? 0 : x + 1, xm = x == 0 ? a.W - 1 : x - 1;
+            const int yp = y + 1 == a.H ? 0 : y + 1, ym = y == 0 ? a.H - 1 : y - 1;
+            const float s = 127.5f;
+            const float x00 = v / s;
+            const float x0p = p[(size_t)y * a.W + xp] / s, xp0 = p[(size_t)yp * a.W + x] / s;
+            const float x0m = p[(size_t)y * a.W + xm] / s, xm0 = p[(size_t)ym * a.W + x] / s;
+            const float xpm = p[(size_t)yp * a.W + xm] / s, xmp = p[(size_t)ym * a.W + xp] / s;
+            const float hb = a.tv_half_beta;
+            // this pixel
+            const float dx = x00 - x0p, dy = x00 - xp0;
+            const float n2 = dx * dx + dy * dy + kEps;
+            sums[0] += hb == 1.f ? n2 : powf(n2, hb);
+            const float dn = hb == 1.f ? 1.f : hb * powf(n2, hb - 1.f);
+            // left neighbour's x-difference and upper neighbour's y-difference point at this pixel
+            const float dxl = x0m - x00, dyl = x0m - xpm;
+            const float n2l = dxl * dxl + dyl * dyl + kEps;
+            const float dnl = hb == 1.f ? 1.f : hb * powf(n2l, hb - 1.f);
+            const float dxu = xm0 - xmp, dyu = xm0 - x00;
+            const float n2u = dxu * dxu + dyu * dyu + kEps;
+            const float dnu = hb == 1.f ? 1.f : hb * powf(n2u, hb - 1.f);
+            const float gx = 2.f * dx * dn, gy = 2.f * dy * dn;
+            float tv = gx + gy;
+            tv -= 2.f * dxl * dnl;
+            tv -= 2.f * dyu * dnu;
+            g = a.tv_scale * tv + g;
+        }
+        if (a.p_scale != 0.f) {
+            const float z = (v + a.mean[c] - 127.5f) / 127.5f;
+            const float az = fabsf(z);
+            const float ap1 = powf(az, a.p_power - 1.f);
+            sums[1] += ap1 * az;
+            const float sg = z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f);
+            g = a.p_scale * (a.p_power * sg * ap1) + g;
+        }
+        if (a.aux != nullptr && a.aux_scale != 0.f) {
+            const float d = (v - a.aux[i]) / 127.5f;
+            sums[2] += d * d;
+            g = a.aux_scale * d + g;
+        }
+        a.grad[i] = g;
+    }
+    block_partials<3>(sums, partials);
+}
+
+int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
+                        const float mean[3], float tv_scale, float tv_power, float p_scale,
+                        float p_power, const float *aux, float aux_scale, double *loss_terms,
+                        float *scratch, size_t scratch_floats) {
+    RegArgs a;
+    a.img = img;
+    a.grad = grad;
+    a.aux = aux;
+    a.H = H;
+    a.W = W;
+    for (int i = 0; i < 3; ++i) a.mean[i] = mean[i];
+    a.tv_scale = tv_scale;
+    a.tv_half_beta = tv_power / 2.f;
+    a.p_scale = p_scale;
+    a.p_power = p_power;
+    a.aux_scale = aux_scale;
+    const int blocks = blocks_for((size_t)3 * H * W);
+    if (scratch_floats < (size_t)3 * blocks) {
+        set_error("regularizers: scratch too small");
+        return STX_ERR_STATE;
+    }
+    regularizers_kernel<<<blocks, 256, 0, s>>>(a, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<3><<<1, 256, 0, s>>>(scratch, blocks, loss_terms);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// ----------------------------------------------------------------------------------- Adam ---
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params,
+                                                   const float *__restrict__ grad,
+                                                   float *__restrict__ g1, float *__restrict__ g2,
+                                                   float *__restrict__ p1, float *__restrict__ avg,
+                                                   size_t n, float lr, float b1, float b2, float bp1,
+                                                   float omb1, float omb2, float ombp1, float c1,
+                                                   float c2, float cp) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float g = grad[i];
+        const float m1 = g1[i] * b1 + omb1 * g;            // EWMA.update: v *= beta; v += (1-beta)*x
+        const float m2 = g2[i] * b2 + omb2 * (g * g);
+        g1[i] = m1;
+        g2[i] = m2;
+        const float step = (m1 / c1) / (sqrtf(m2 / c2) + kEps);   // optimizers.py:37
+        const float p = params[i] + (-lr) * step;                  // saxpy(-step_size, step, params)
+        params[i] = p;
+        const float a = p1[i] * bp1 + ombp1 * p;
+        p1[i] = a;
+        avg[i] = a / cp;
+    }
+}
+
+int adam_launch(hipStream_t s, float *params, const float *grad, float *g1, float *g2, float *p1,
+                float *avg, size_t n, float lr, float b1, float b2, float bp1, float c1, float c2,
+                float cp) {
+    // (1 - beta) is formed in double like the reference's Python scalar, then cast to float32
+    adam_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(
+        params, grad, g1, g2, p1, avg, n, lr, b1, b2, bp1, (float)(1.0 - (double)b1),
+        (float)(1.0 - (double)b2), (float)(1.0 - (double)bp1), c1, c2, cp);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// --------------------------------------------------------------------------------- BLAS-1 ---
+template <bool ABS>
+__global__ __launch_bounds__(256) void dot_kernel(const float *__restrict__ x,
+                                                  const float *__restrict__ y, size_t n,
+                                                  float *__restrict__ partials) {
+    float acc[1] = {0.f};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        acc[0] += ABS ? fabsf(x[i]) : x[i] * y[i];
+    block_partials<1>(acc, partials);
+}
+
+int dot_launch(hipStream_t s, const float *x, const float *y, size_t n, double *out_dev,
+               float *scratch, size_t scratch_floats) {
+    const int blocks = blocks_for(n);
+    if (scratch_floats < (size_t)blocks) return STX_ERR_STATE;
+    dot_kernel<false><<<blocks, 256, 0, s>>>(x, y, n, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<1><<<1, 256, 0, s>>>(scratch, blocks, out_dev);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int abs_sum_launch(hipStream_t s, const float *x, size_t n, double *out_dev, float *scratch,
+                   size_t scratch_floats) {
+    const int blocks = blocks_for(n);
+    if (scratch_floats < (size_t)blocks) return STX_ERR_STATE;
+    dot_kernel<true><<<blocks, 256, 0, s>>>(x, x, n, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<1><<<1, 256, 0, s>>>(scratch, blocks, out_dev);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float *__restrict__ x,
+                                                   float *__restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = a * x[i] + y[i];
+}
+
+int axpy_launch(hipStream_t s, float a, const float *x, float *y, size_t n) {
+    axpy_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(a, x, y, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float a, float *__restrict__ x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        x[i] = a * x[i];
+}
+
+int scale_launch(hipStream_t s, float a, float *x, size_t n) {
+    scale_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(a, x, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// ------------------------------------------------------------------------------ statistics ---
+__global__ __launch_bounds__(256) void step_stats_kernel(const float *__restrict__ avg,
+                                                         float *__restrict__ old, int H, int W,
+                                                         float *__restrict__ partials) {
+    const size_t plane = (size_t)H * W, total = 3 * plane;
+    float sums[2] = {0.f, 0.f};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % W;
+        const int y = (i / W) % H;
+        const size_t base = i - (size_t)y * W - x;
+        const float v = avg[i];
+        sums[0] += fabsf(v - old[i]);
+        const float xd = v - avg[base + (size_t)y * W + (x + 1 == W ? 0 : x + 1)];
+        const float yd = v - avg[base + (size_t)(y + 1 == H ? 0 : y + 1) * W + x];
+        sums[1] += xd * xd + yd * yd;
+        old[i] = v;
+    }
+    block_partials<2>(sums, partials);
+}
+
+int step_stats_launch(hipStream_t s, const float *avg, float *old, int H, int W, double *out_dev,
+                      float *scratch, size_t scratch_floats) {
+    const int blocks = blocks_for((size_t)3 * H * W);
+    if (scratch_floats < (size_t)2 * blocks) return STX_ERR_STATE;
+    step_stats_kernel<<<blocks, 256, 0, s>>>(avg, old, H, W, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<2><<<1, 256, 0, s>>>(scratch, blocks, out_dev);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// ----------------------------------------------------------------------------------- uint8 ---
+__global__ __launch_bounds__(256) void to_u8_kernel(const float *__restrict__ img, int H, int W,
+                                                    float m0, float m1, float m2,
+                                                    uint8_t *__restrict__ out) {
+    const size_t plane = (size_t)H * W;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+        const float b = fminf(fmaxf(img[i] + m0, 0.f), 255.f);
+        const float g = fminf(fmaxf(img[plane + i] + m1, 0.f), 255.f);
+        const float r = fminf(fmaxf(img[2 * plane + i] + m2, 0.f), 255.f);
+        out[3 * i + 0] = (uint8_t)r;    // np.uint8() truncates toward zero
+        out[3 * i + 1] = (uint8_t)g;
+        out[3 * i + 2] = (uint8_t)b;
+    }
+}
+
+int to_u8_launch(hipStream_t s, const float *img, int H, int W, const float mean[3], uint8_t *out) {
+    const size_t plane = (size_t)H * W;
+    to_u8_kernel<<<(int)std::min<size_t>((plane + 255) / 256, 8192), 256, 0, s>>>(
+        img, H, W, mean[0], mean[1], mean[2], out);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+}  // namespace stx

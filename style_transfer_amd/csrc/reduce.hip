@@ -1,0 +1,162 @@
+// Loss reductions and gradient injection for the tapped layers of a tile (HBM-bound passes).
+//
+// Reference: CaffeModel.eval_sc_grad_tile, style_transfer.py:575-593 with num_utils.py
+// normalize (85-87), norm2 (69-71), saxpy (26-29):
+//   content:  c = F - Fc[:, window];  loss += lw*cw * 1/2 sum c^2;  diff += lw*cw * c / (mean|c| + EPS)
+//   style:    S = sym(tril(G - Gs)) F;                              diff += lw*sw/n * S / (mean|S| + EPS)
+// The content residual is never materialised: one pass reduces sum c^2 and sum |c|, the
+// injection pass recomputes F - Fc.  The content map Fc is the FULL-image map; the worker's
+// physical roll of it (style_transfer.py:234,647-655) is applied here as an index offset with
+// wrap-around.  All reductions write per-workgroup partials that are then added in a fixed
+// order, so results do not depend on scheduling.
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace stx {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Rolled content value at tile-feature position (c, y, x):
+// roll2(Fc, (sx, sy))[c][oy + y][ox + x] = Fc[c][(oy + y - sy) mod ch][(ox + x - sx) mod cw]
+__device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, int y, int x) {
+    int yy = (w.oy + y - w.sy) % w.ch;
+    int xx = (w.ox + x - w.sx) % w.cw;
+    if (yy < 0) yy += w.ch;
+    if (xx < 0) xx += w.cw;
+    return ((size_t)c * w.ch + yy) * w.cw + xx;
+}
+
+constexpr int kRedBlocks = 1024;
+
+__global__ __launch_bounds__(256) void content_sums_kernel(const float *__restrict__ feat,
+                                                           const float *__restrict__ content,
+                                                           ContentWindow w,
+                                                           float *__restrict__ partials) {
+    __shared__ float red[2][4];
+    const size_t total = (size_t)w.C * w.fh * w.fw;
+    float sq = 0.f, ab = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % w.fw;
+        const int y = (i / w.fw) % w.fh;
+        const int c = i / ((size_t)w.fw * w.fh);
+        const float d = feat[i] - content[content_index(w, c, y, x)];
+        sq += d * d;
+        ab += fabsf(d);
+    }
+    sq = wave_sum(sq);
+    ab = wave_sum(ab);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sq;
+        red[1][threadIdx.x >> 6] = ab;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partials[gridDim.x + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void sum_two_kernel(const float *__restrict__ partials, int n, float *__restrict__ out) {
+    __shared__ float red[256];
+    for (int which = 0; which < 2; ++which) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += partials[which * n + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[which] = red[0];
+        __syncthreads();
+    }
+}
+
+// `sums` doubles as scratch: sums[0..1] receive the results, the partials live behind them
+// (the engine reserves 2 + 2*kRedBlocks floats per content tap).
+int content_sums_launch(hipStream_t s, const float *feat, const float *content,
+                        const ContentWindow &win, float *sums) {
+    const size_t total = (size_t)win.C * win.fh * win.fw;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, kRedBlocks);
+    float *partials = sums + 2;
+    content_sums_kernel<<<blocks, 256, 0, s>>>(feat, content, win, partials);
+    STX_CHECK_LAUNCH();
+    sum_two_kernel<<<1, 256, 0, s>>>(partials, blocks, sums);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void inject_style_kernel(float *__restrict__ diff,
+                                                           const float *__restrict__ sgrad, size_t n,
+                                                           const float *__restrict__ abs_sum,
+                                                           float coef) {
+    // normalize(): x *= 1 / (sum|x| / size + EPS)   (num_utils.py:85-87)
+    const float scale = coef * (1.0f / (abs_sum[0] / (float)n + kEps));
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = scale * sgrad[i];
+        diff[i] = ACC ? diff[i] + v : v;
+    }
+}
+
+int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
+                        const float *abs_sum, const float *, int, float coef, bool accumulate) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    if (accumulate)
+        inject_style_kernel<true><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef);
+    else
+        inject_style_kernel<false><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__ diff,
+                                                             const float *__restrict__ feat,
+                                                             const float *__restrict__ content,
+                                                             ContentWindow w,
+                                                             const float *__restrict__ sums,
+                                                             float coef) {
+    const size_t total = (size_t)w.C * w.fh * w.fw;
+    const float scale = coef * (1.0f / (sums[1] / (float)total + kEps));
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % w.fw;
+        const int y = (i / w.fw) % w.fh;
+        const int c = i / ((size_t)w.fw * w.fh);
+        const float v = scale * (feat[i] - content[content_index(w, c, y, x)]);
+        diff[i] = ACC ? diff[i] + v : v;
+    }
+}
+
+int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
+                          const ContentWindow &win, const float *sums, float coef,
+                          bool accumulate) {
+    const size_t total = (size_t)win.C * win.fh * win.fw;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (accumulate)
+        inject_content_kernel<true><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef);
+    else
+        inject_content_kernel<false><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+__global__ __launch_bounds__(256) void relu_kernel(float *__restrict__ x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        x[i] = fmaxf(x[i], 0.f);
+}
+
+int relu_inplace_launch(hipStream_t s, float *x, size_t n) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    relu_kernel<<<blocks, 256, 0, s>>>(x, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+}  // namespace stx

@@ -1,0 +1,273 @@
+"""Python face of one libstx tile engine (one GPU).
+
+Mirrors the server side of the reference's tile-worker protocol: the three requests a
+``TileWorker`` answers (``style_transfer.py:215-259``) become three methods with the same
+argument meaning --
+
+    FeatureMapRequest(img, layers)                    -> features_tile(img, layers)
+    SCGradRequest(img, roll, start, content_layers,   -> sc_grad_tile(img, start, roll, ...)
+                  style_layers, dd_layers, layer_weights,
+                  content_weight, style_weight, dd_weight)
+    SetContentsAndStyles(contents, styles)            -> set_contents_and_styles(contents, styles)
+
+-- and the arithmetic behind them (``CaffeModel.eval_features_tile`` / ``eval_sc_grad_tile``,
+``style_transfer.py:421-427,556-612``) runs in the HIP kernels of libstx.  Arrays may be numpy
+(host) or ``DeviceArray`` (resident on the engine's GPU).
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import lib
+from .netspec import NetSpec
+
+_TYPE_CODES = {'Input': lib.LAYER_INPUT, 'Convolution': lib.LAYER_CONV, 'ReLU': lib.LAYER_RELU,
+               'Pooling': lib.LAYER_POOL}
+
+
+class DeviceArray:
+    """A float32 (or uint8) array living on an engine's GPU."""
+
+    def __init__(self, engine, shape, dtype=np.float32):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = ctypes.c_void_p()
+        lib.call('stx_malloc', engine.handle, self.nbytes, ctypes.byref(ptr))
+        self.ptr = ptr.value
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, self.dtype)
+        assert host.shape == self.shape, (host.shape, self.shape)
+        lib.call('stx_memcpy_async', self.engine.handle, self.ptr, lib.DEVICE, host.ctypes.data,
+                 lib.HOST, self.nbytes)
+        self.engine.sync()
+        return self
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        lib.call('stx_memcpy_async', self.engine.handle, self.ptr, lib.DEVICE, other.ptr,
+                 lib.DEVICE, self.nbytes)
+        return self
+
+    def zero(self):
+        lib.call('stx_memset_async', self.engine.handle, self.ptr, 0, self.nbytes)
+        return self
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        lib.call('stx_memcpy_async', self.engine.handle, out.ctypes.data, lib.HOST, self.ptr,
+                 lib.DEVICE, self.nbytes)
+        self.engine.sync()
+        return out
+
+    def free(self):
+        if self.ptr and self.engine.handle:
+            lib.call('stx_free', self.engine.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+def _as_arg(arr):
+    """(pointer, mem tag, keep-alive object) for a numpy array or DeviceArray."""
+    if isinstance(arr, DeviceArray):
+        return arr.ptr, lib.DEVICE, arr
+    host = np.ascontiguousarray(arr, np.float32)
+    return host.ctypes.data, lib.HOST, host
+
+
+class PendingTile:
+    """Result of an asynchronous sc_grad_tile: valid after ``engine.sync()``."""
+
+    def __init__(self, grad, keep):
+        self._loss = ctypes.c_double(float('nan'))
+        self.grad = grad
+        self._keep = keep
+
+    @property
+    def loss(self):
+        return self._loss.value
+
+
+class TileEngine:
+    """One GPU's worker: the network, its weights and the current targets."""
+
+    def __init__(self, net, device=0, weights=None):
+        assert isinstance(net, NetSpec)
+        self.net = net
+        self.device = device
+        self.handle = None
+        descs = (lib.LayerDesc * len(net.layers))()
+        self._strings = []
+        for d, lay in zip(descs, net.layers):
+            d.name = self._cstr(lay.name)
+            d.type = _TYPE_CODES[lay.type]
+            d.bottom = self._cstr(lay.bottom) if lay.bottom else None
+            d.top = self._cstr(lay.top)
+            d.num_output = lay.num_output if lay.type != 'Input' else \
+                (lay.shape[1] if lay.shape else 3)
+            d.kernel_size, d.pad, d.stride = lay.kernel_size, lay.pad, lay.stride
+            d.pool_mode = lib.POOL_AVE if lay.pool == 'AVE' else lib.POOL_MAX
+        handle = ctypes.c_void_p()
+        lib.call('stx_engine_create', device, descs, len(net.layers), ctypes.byref(handle))
+        self.handle = handle
+        self._info = {b: net.layer_info(b) for b in net.blob_names()}
+        self.n_styles = 0
+        if weights:
+            for name, (w, b) in weights.items():
+                self.set_weights(name, w, b)
+
+    def _cstr(self, s):
+        b = s.encode()
+        self._strings.append(b)
+        return b
+
+    def close(self):
+        if self.handle:
+            lib.load().stx_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    # ------------------------------------------------------------------------------ basics
+    def sync(self):
+        lib.call('stx_sync', self.handle)
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, host, dtype=np.float32):
+        host = np.ascontiguousarray(host, dtype)
+        return DeviceArray(self, host.shape, dtype).set(host)
+
+    def layer_info(self, layer):
+        """(scale, channels) -- CaffeModel.layer_info, style_transfer.py:415-419."""
+        return self._info[layer]
+
+    def feature_shape(self, layer, th, tw):
+        scale, ch = self._info[layer]
+        h, w = th, tw
+        s = 1
+        while s < scale:          # one ceil-mode halving per pooling stage
+            h, w, s = (h + 1) // 2, (w + 1) // 2, s * 2
+        return ch, h, w
+
+    def set_weights(self, conv_layer, w, b):
+        w = np.ascontiguousarray(w, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        lib.call('stx_set_conv_weights', self.handle, conv_layer.encode(), w.ctypes.data,
+                 b.ctypes.data, lib.HOST)
+
+    # ------------------------------------------------------------- SetContentsAndStyles
+    def set_contents_and_styles(self, contents, styles):
+        """contents: list of {layer: [C,h,w] full-image feature map}; styles: list of
+        {layer: [C,C] lower-triangular Gram} (style_transfer.py:243-254)."""
+        keep = []
+        n_c = sum(len(c) for c in contents)
+        n_s = sum(len(s) for s in styles)
+        ctargets = (lib.ContentTarget * max(1, n_c))()
+        starget = (lib.StyleTarget * max(1, n_s))()
+        i = 0
+        for ci, content in enumerate(contents):
+            for layer, feat in content.items():
+                ptr, mem, obj = _as_arg(feat)
+                keep.append(obj)
+                t = ctargets[i]
+                t.content_index, t.layer = ci, self._cstr(layer)
+                t.channels, t.height, t.width = obj.shape
+                t.features, t.mem = ptr, mem
+                i += 1
+        i = 0
+        for si, style in enumerate(styles):
+            for layer, gram in style.items():
+                ptr, mem, obj = _as_arg(gram)
+                keep.append(obj)
+                t = starget[i]
+                t.style_index, t.layer, t.channels = si, self._cstr(layer), obj.shape[0]
+                t.gram, t.mem = ptr, mem
+                i += 1
+        lib.call('stx_set_contents_and_styles', self.handle, ctargets, n_c, starget, n_s)
+        self.n_styles = len(styles)
+
+    # --------------------------------------------------------------------- FeatureMapRequest
+    def features_tile(self, img, layers):
+        """Post-ReLU feature maps of one tile: {layer: [C, ceil(th/s), ceil(tw/s)] ndarray}."""
+        ptr, mem, keep = _as_arg(img)
+        th, tw = keep.shape[-2:]
+        outs = [np.empty(self.feature_shape(l, th, tw), np.float32) for l in layers]
+        names = (ctypes.c_char_p * len(layers))(*[l.encode() for l in layers])
+        ptrs = (ctypes.c_void_p * len(layers))(*[o.ctypes.data for o in outs])
+        lib.call('stx_features_tile', self.handle, ptr, mem, th, tw, names, len(layers), ptrs,
+                 lib.HOST)
+        self.sync()
+        return dict(zip(layers, outs))
+
+    # --------------------------------------------------------------------------- SCGradRequest
+    def _taps(self, content_layers, style_layers, layer_weights, content_weight, style_weight):
+        names = list(dict.fromkeys(list(content_layers) + list(style_layers)))
+        taps = (lib.Tap * len(names))()
+        for t, name in zip(taps, names):
+            t.layer = self._cstr(name)
+            t.layer_weight = float(layer_weights.get(name, 1.0)) if layer_weights else 1.0
+            t.is_content = int(name in content_layers)
+            t.content_weight = float(content_weight.get(name, 0.0)) if t.is_content else 0.0
+            t.is_style = int(name in style_layers)
+            t.style_weight = float(style_weight.get(name, 0.0)) if t.is_style else 0.0
+        return taps, len(names)
+
+    def sc_grad_tile_async(self, img, start, roll, content_layers, style_layers, layer_weights,
+                           content_weight, style_weight, grad_out=None):
+        """Enqueues one tile evaluation; returns a PendingTile (read it after ``sync()``)."""
+        ptr, mem, keep = _as_arg(img)
+        th, tw = keep.shape[-2:]
+        if grad_out is None:
+            grad_out = np.empty((3, th, tw), np.float32)
+        gptr, gmem, gkeep = (grad_out.ptr, lib.DEVICE, grad_out) \
+            if isinstance(grad_out, DeviceArray) else (grad_out.ctypes.data, lib.HOST, grad_out)
+        taps, n_taps = self._taps(content_layers, style_layers, layer_weights, content_weight,
+                                  style_weight)
+        roll_c = (ctypes.c_int * 2)(int(roll[0]), int(roll[1])) if roll is not None \
+            else (ctypes.c_int * 2)(0, 0)
+        start_c = (ctypes.c_int * 2)(int(start[0]), int(start[1]))
+        pending = PendingTile(gkeep, (keep, taps))
+        lib.call('stx_sc_grad_tile', self.handle, ptr, mem, th, tw, roll_c, start_c, taps, n_taps,
+                 ctypes.byref(pending._loss), gptr, gmem, 0)
+        return pending
+
+    def sc_grad_tile(self, img, start, roll, content_layers, style_layers, layer_weights,
+                     content_weight, style_weight):
+        """(loss, grad[3,th,tw]) of one tile -- CaffeModel.eval_sc_grad_tile with the worker's
+        content roll (style_transfer.py:230-241,556-612)."""
+        pending = self.sc_grad_tile_async(img, start, roll, content_layers, style_layers,
+                                          layer_weights, content_weight, style_weight)
+        self.sync()
+        return pending.loss, pending.grad
+
+    def gram_matrix(self, feat):
+        """Lower-triangular Gram of a [C,h,w] feature map (num_utils.py:143-147)."""
+        ptr, mem, keep = _as_arg(feat)
+        c = keep.shape[0]
+        hw = int(np.prod(keep.shape[1:]))
+        out = np.empty((c, c), np.float32)
+        lib.call('stx_gram_matrix', self.handle, ptr, mem, c, hw, out.ctypes.data, lib.HOST)
+        return out
+
+    def last_tile_ms(self):
+        ms = ctypes.c_float(0)
+        lib.call('stx_last_tile_ms', self.handle, ctypes.byref(ms))
+        return ms.value

@@ -1,0 +1,66 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/stx.h declares, and the
+host-side network description matches the reference's tables."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from style_transfer_amd import lib, netspec
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(REPO, 'include', 'stx.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(stx_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 30
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in names:
+        assert hasattr(so, name), 'libstx.so does not export %s' % name
+    bound = set(lib.SIGNATURES) | set(lib.NON_STATUS)
+    assert set(names) == bound, set(names) ^ bound
+
+
+def test_library_loads_and_reports_errors_without_gpu():
+    assert lib.version().startswith('libstx')
+    n = lib.device_count()
+    assert n >= 0
+    # NULL arguments are rejected with a status, never a crash
+    assert lib.load().stx_sync(None) == -1
+
+
+def test_builtin_nets_match_reference_shape_tables():
+    # VGG19_SHAPES / VGG16_SHAPES of style_transfer.py:1030-1073
+    v19 = netspec.builtin_net('vgg19.prototxt').shapes()
+    assert list(v19)[:4] == ['conv1_1', 'conv1_2', 'pool1', 'conv2_1'] and len(v19) == 21
+    assert v19['conv4_2'] == (512, 28, 28) and v19['pool5'] == (512, 7, 7)
+    v16 = netspec.builtin_net('vgg16').shapes()
+    assert len(v16) == 18 and 'conv3_4' not in v16 and v16['conv5_3'] == (512, 14, 14)
+    net = netspec.builtin_net('vgg19')
+    assert net.layer_info('conv4_2') == (8, 512) and net.layer_info('pool5') == (32, 512)
+    assert all(l.pool == 'AVE' for l in netspec.builtin_net('vgg16_avgpool').layers
+               if l.type == 'Pooling')
+    big = netspec.builtin_net('vgg19_big')
+    conv2_1 = [l for l in big.layers if l.name == 'conv2_1'][0]
+    assert conv2_1.bottom == 'conv1_2' and big.layer_info('conv2_1')[0] == 1
+
+
+def test_prototxt_round_trip():
+    net = netspec.builtin_net('vgg19_avgpool')
+    again = netspec.parse_prototxt(netspec.to_prototxt(net))
+    assert [l.as_dict() for l in again.layers] == [l.as_dict() for l in net.layers]
+    with pytest.raises(ValueError):
+        netspec.parse_prototxt('layer { name: "x" type: "Softmax" bottom: "a" top: "b" }')
+
+
+def test_pooled_len_is_caffe_ceil_mode():
+    for n in range(1, 70):
+        assert netspec.pooled_len(n) == (int(np.ceil((n - 2) / 2)) + 1 if n >= 2 else 1)
