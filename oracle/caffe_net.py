@@ -190,6 +190,20 @@ class Net:
                 top.data[0] = y
                 self._aux[lay['name']] = aux
 
+    def load_activations(self, data):
+        """Overwrites blob data with externally computed activations ({blob: [C,H,W]}) and
+        re-derives the MAX-pool argmax from them.  Used by the GPU parity tests to give the
+        oracle's backward pass the same discrete decisions (argmax routing, ReLU masks) as
+        the implementation under test: those are discontinuous in the activations, so two
+        float32 forward passes that agree to 1e-6 may still disagree on a near-tie."""
+        for name, arr in data.items():
+            self.blobs[name].data[0] = arr
+        for lay in self.layers:
+            if lay['type'] == 'Pooling' and lay['bottom'] in data:
+                _, aux = L.pool_forward(self.blobs[lay['bottom']].data[0], lay['pool'],
+                                        lay['kernel_size'], lay['stride'])
+                self._aux[lay['name']] = aux
+
     def backward(self, start=None, end=None):
         """Runs layers start..end in reverse (both inclusive, start is the later layer)."""
         i1, i0 = self._index(start, len(self.layers) - 1), self._index(end, 0)

@@ -63,7 +63,8 @@ class OracleModel:
 
     # ---- style_transfer.py:556-612
     def sc_grad_tile(self, tile, start, content_layers, style_layers, layer_weights,
-                     content_weight, style_weight):
+                     content_weight, style_weight, activations=None):
+        """``activations`` (test-only, see Net.load_activations) replaces the forward results."""
         net = self.net
         order = self.deep_to_shallow(list(content_layers) + list(style_layers))
         net.blobs['data'].reshape(1, 3, *tile.shape[-2:])
@@ -73,6 +74,8 @@ class OracleModel:
             net.blobs[b].diff[...] = 0
         net.forward(end=order[0])
         np.maximum(net.blobs[order[0]].data, 0, out=net.blobs[order[0]].data)
+        if activations is not None:
+            net.load_activations(activations)
         start = np.asarray(start)
         loss = 0.0
         for i, b in enumerate(order):

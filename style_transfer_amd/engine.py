@@ -160,6 +160,8 @@ class TileEngine:
         return self._info[layer]
 
     def feature_shape(self, layer, th, tw):
+        if layer not in self._info:
+            raise lib.StxError('feature_shape', -1, "unknown layer '%s'" % layer)
         scale, ch = self._info[layer]
         h, w = th, tw
         s = 1

@@ -1,9 +1,17 @@
 """The per-tile hot path (stx_features_tile / stx_sc_grad_tile through the C ABI) against the
 golden vectors produced by the reference's own Python and against the numpy oracle.
 
-Stated tolerance: per-pixel |grad - ref| <= 1e-4 * max|ref| and loss within 1e-4 relative
-(float32 end to end on both sides; only the summation order inside convolutions, Grams and
-reductions differs)."""
+Stated tolerances (float32 on both sides; only summation order differs):
+  * activations of every blob and the loss:      |a - ref| <= 1e-5 * max|ref|
+  * gradient, AVE-pool nets (continuous):         per pixel |g - ref| <= 1e-5 * max|ref|
+  * gradient, MAX-pool nets: the gradient is a DISCONTINUOUS function of the activations (argmax
+    routing of max pooling, `> 0` ReLU masks).  Two float32 forward passes that agree to 1e-6
+    still pick different winners in windows whose two largest values differ by less than that
+    (a few windows per tile on these fixtures), and each flipped window moves O(1e-3) of the
+    gradient norm.  So the check is two-sided: (a) with the oracle's backward pass given the
+    GPU's activations (identical discrete decisions) the gradient must agree per pixel to
+    1e-5 * max|ref|; (b) against the untouched reference vectors the relative L2 error must stay
+    below 1e-2, i.e. only a handful of windows may have flipped."""
 
 import numpy as np
 import pytest
@@ -12,7 +20,13 @@ from tests.gpu_helpers import gpu_engine, max_rel
 from tests.helpers import (DEFAULT_STYLE_LAYERS, make_oracle, normalized_weights, u8_to_params)
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
+TIGHT = 1e-5
+FLIP_L2 = 1e-2
+
+
+def l2_rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
 def _targets(golden, tag, model):
@@ -28,6 +42,29 @@ def _targets(golden, tag, model):
     return g, om, (content_layers, content_weight, style_layers, style_weight)
 
 
+def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, continuous):
+    """GPU tile evaluation vs the oracle; returns the GPU (loss, grad)."""
+    loss, grad = eng.sc_grad_tile(tile, start, roll, cl, sl, lw, cw, sw)
+    deepest = om.deep_to_shallow(cl + sl)[0]
+    blobs = om.blob_names[:om.blob_names.index(deepest) + 1]
+    acts = eng.features_tile(tile, blobs)
+    om.roll_contents(roll)
+    try:
+        ref_loss, ref_grad = om.sc_grad_tile(tile, start, cl, sl, lw, cw, sw)
+        ref_acts = {b: om.net.blobs[b].data[0].copy() for b in blobs}
+        same_loss, same_grad = om.sc_grad_tile(tile, start, cl, sl, lw, cw, sw, activations=acts)
+    finally:
+        om.roll_contents(-np.asarray(roll))
+    for b in blobs:
+        assert max_rel(acts[b], ref_acts[b]) < TIGHT, b
+    assert loss == pytest.approx(ref_loss, rel=TIGHT)
+    assert loss == pytest.approx(same_loss, rel=TIGHT)
+    assert max_rel(grad, same_grad) < TIGHT
+    # ReLU masks are discontinuous too, so even AVE-pool nets may flip an element on noisy inputs
+    assert l2_rel(grad, ref_grad) < (1e-3 if continuous else FLIP_L2)
+    return loss, grad
+
+
 @pytest.mark.parametrize('tag,model', [('vgg19', 'vgg19'), ('vgg16avg', 'vgg16_avgpool')])
 def test_sc_grad_tile_matches_reference_vectors(golden, tag, model):
     g, om, (cl, cw, sl, sw) = _targets(golden, tag, model)
@@ -35,14 +72,18 @@ def test_sc_grad_tile_matches_reference_vectors(golden, tag, model):
     eng.set_contents_and_styles(om.contents, om.styles)
     lw = {'conv3_1': float(g['lw_conv3_1'])}
     tile = np.ascontiguousarray(g['img_rolled'][:, 8:48, 16:72])
+    continuous = 'avg' in model
     # the golden single tile was evaluated with the worker's content maps un-rolled (roll 0)
-    loss, grad = eng.sc_grad_tile(tile, (8, 16), (0, 0), cl, sl, lw, cw, sw)
-    assert loss == pytest.approx(float(g['single.loss']), rel=TOL)
-    assert max_rel(grad, g['single.grad']) < TOL
+    loss, grad = check_tile(eng, om, tile, (8, 16), (0, 0), cl, cw, sl, sw, lw, continuous)
+    assert loss == pytest.approx(float(g['single.loss']), rel=TIGHT)
+    if continuous:
+        assert max_rel(grad, g['single.grad']) < TIGHT
+    else:
+        assert l2_rel(grad, g['single.grad']) < FLIP_L2
     feats = eng.features_tile(tile, ['pool1', 'conv5_1'])
-    assert max_rel(feats['conv5_1'], g['single.feat_conv5_1']) < TOL
+    assert max_rel(feats['conv5_1'], g['single.feat_conv5_1']) < TIGHT
     assert feats['pool1'].sum(dtype=np.float64) == pytest.approx(float(g['single.feat_pool1_sum']),
-                                                                 rel=TOL)
+                                                                 rel=TIGHT)
 
 
 @pytest.mark.parametrize('tag,model', [('vgg19', 'vgg19'), ('vgg16avg', 'vgg16_avgpool')])
@@ -54,21 +95,26 @@ def test_tiled_sc_grad_with_roll_matches_reference_vectors(golden, tag, model):
     eng.set_contents_and_styles(om.contents, om.styles)
     lw = {'conv3_1': float(g['lw_conv3_1'])}
     img = g['img_rolled']
+    continuous = 'avg' in model
     grad = np.zeros_like(img)
     loss = 0.0
     for (y0, y1, x0, x1) in tile_grid(img.shape[-2:], int(g['tile_size'])):
-        tl, tg = eng.sc_grad_tile(np.ascontiguousarray(img[:, y0:y1, x0:x1]), (y0, x0), g['roll'],
-                                  cl, sl, lw, cw, sw)
+        tl, tg = check_tile(eng, om, np.ascontiguousarray(img[:, y0:y1, x0:x1]), (y0, x0),
+                            g['roll'], cl, cw, sl, sw, lw, continuous)
         loss += tl
         grad[:, y0:y1, x0:x1] = tg
-    assert loss == pytest.approx(float(g['loss']), rel=TOL)
-    assert max_rel(grad, g['grad']) < TOL
+    assert loss == pytest.approx(float(g['loss']), rel=TIGHT)
+    if continuous:
+        assert max_rel(grad, g['grad']) < TIGHT
+    else:
+        assert l2_rel(grad, g['grad']) < FLIP_L2
 
 
-@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96)])
-def test_sc_grad_tile_odd_sizes_against_oracle(th, tw):
-    om, _ = make_oracle('vgg19')
-    eng = gpu_engine('vgg19')
+@pytest.mark.parametrize('model', ['vgg19', 'vgg16_avgpool'])
+@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96), (33, 130)])
+def test_sc_grad_tile_odd_sizes_against_oracle(model, th, tw):
+    om, _ = make_oracle(model)
+    eng = gpu_engine(model)
     rng = np.random.RandomState(th)
     cl, cw = normalized_weights(['conv4_2'], 0.05)
     sl, sw = normalized_weights(DEFAULT_STYLE_LAYERS, 1)
@@ -78,12 +124,23 @@ def test_sc_grad_tile_odd_sizes_against_oracle(th, tw):
     om.contents = [om.prepare_features(full, cl, 512)]
     eng.set_contents_and_styles(om.contents, om.styles)
     tile = np.ascontiguousarray(full[:, 16:16 + th, 8:8 + tw])
-    roll = (-16, 24)
-    om.roll_contents(roll)
-    ref_loss, ref_grad = om.sc_grad_tile(tile, (16, 8), cl, sl, {}, cw, sw)
-    loss, grad = eng.sc_grad_tile(tile, (16, 8), roll, cl, sl, {}, cw, sw)
-    assert loss == pytest.approx(ref_loss, rel=TOL)
-    assert max_rel(grad, ref_grad) < TOL
+    check_tile(eng, om, tile, (16, 8), (-16, 24), cl, cw, sl, sw, {}, 'avg' in model)
+
+
+def test_non_default_taps(golden):
+    """Content on a pooling blob, style on conv1_2/conv3_3 only, weighted layers."""
+    om, _ = make_oracle('vgg16_avgpool')
+    eng = gpu_engine('vgg16_avgpool')
+    rng = np.random.RandomState(3)
+    cl, cw = ['pool3'], {'pool3': 0.3}
+    sl, sw = ['conv1_2', 'conv3_3'], {'conv1_2': 0.25, 'conv3_3': 0.75}
+    full = rng.uniform(-110, 120, (3, 72, 88)).astype(np.float32)
+    style = rng.uniform(-110, 120, (3, 40, 44)).astype(np.float32)
+    om.styles = [om.style_grams([style], sl, 512)]
+    om.contents = [om.prepare_features(full, cl, 512)]
+    eng.set_contents_and_styles(om.contents, om.styles)
+    tile = np.ascontiguousarray(full[:, 8:8 + 56, 16:16 + 64])
+    check_tile(eng, om, tile, (8, 16), (0, 0), cl, cw, sl, sw, {'conv1_2': 2.0, 'pool3': 0.5}, True)
 
 
 def test_errors_are_reported_not_fatal():
