@@ -1,0 +1,138 @@
+"""Command-line driver, flag-compatible with the reference's ``style_transfer.py`` CLI
+(``style_transfer.py:1076-1163``): same options (``config_system.py``), the same per-step
+console line and ``<RUN>_log.csv`` columns (``style_transfer.py:101-130,950-951``), the same
+PNG comment block (``style_transfer.py:1003-1010``).  The web / GUI live views are not part of
+the accelerated path; ``--display`` is accepted and ignored.
+"""
+
+import csv
+from datetime import datetime
+import sys
+import time
+
+import numpy as np
+from PIL import Image, PngImagePlugin
+
+from . import lib
+from .config_system import parse_args
+from .farm import TileFarm
+from .netspec import load_net
+from .transfer import StyleTransfer
+from .weights import load_weights
+
+
+class StatLogger:
+    """Per-iteration rows for ``<RUN>_log.csv`` (style_transfer.py:101-130)."""
+
+    def __init__(self):
+        self.rows, self.start = [], None
+
+    def new_row(self, **kw):
+        if self.start is None:
+            self.start = time.perf_counter()
+        kw.update(iteration=len(self.rows), time=time.perf_counter() - self.start)
+        self.rows.append(kw)
+
+    def update(self, **kw):
+        self.rows[-1].update(kw)
+
+    def dump(self, path):
+        fields = ['iteration', 'scale', 'step', 'time']
+        for row in self.rows:
+            fields += [k for k in row if k not in fields]
+        with open(path, 'w', newline='') as f:
+            writer = csv.DictWriter(f, fieldnames=fields)
+            writer.writeheader()
+            writer.writerows(self.rows)
+
+
+class Progress:
+    """Prints the reference's step line and keeps the statistics (style_transfer.py:912-960)."""
+
+    def __init__(self, run, stats, save_every=0):
+        self.run, self.stats, self.save_every = run, stats, save_every
+        self.prev_t, self.step, self.steps = None, 0, 0
+
+    def set_steps(self, steps):
+        self.steps = steps
+
+    def __call__(self, step, update_size, loss, tv_loss, transfer):
+        now = time.perf_counter()
+        self.step += 1
+        dt = 0 if self.prev_t is None else now - self.prev_t
+        self.prev_t = now
+        state = transfer.state
+        self.stats.new_row(scale=state.scale, step=step - 1, content_h=transfer.img.shape[1],
+                           content_w=transfer.img.shape[2])
+        self.stats.update(update_size=update_size, loss=loss, tv_norm=tv_loss)
+        if self.save_every and self.step % self.save_every == 0:
+            transfer.current_output.save(self.run + '_out_%04d.png' % self.step)
+        print('Step %d, time: %.2f s, update: %.2f, loss: %e, tv: %.2f' %
+              (step, dt, update_size, loss, tv_loss), flush=True)
+
+
+def image_comment(args, argv):
+    s = 'Created with style_transfer_amd (CLI-compatible with crowsonkb/style_transfer).\n\n'
+    s += 'Command line: style_transfer.py ' + ' '.join(argv) + '\n\nParameters:\n'
+    for key in sorted(args):
+        s += '%s: %s\n' % (key, getattr(args, key))
+    return s
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    from argparse import Namespace
+    state = Namespace()
+    args = parse_args(state, argv)
+    start_time = time.perf_counter()
+    now = datetime.now()
+    run = '%02d%02d%02d_%02d%02d%02d' % (now.year % 100, now.month, now.day, now.hour,
+                                         now.minute, now.second)
+    print('Run %s started.' % run)
+    net = load_net(args.model)
+    if args.list_layers:
+        print('Layers:')
+        for layer, shape in net.shapes().items():
+            print('% 25s %s' % (layer, shape))
+        return 0
+    n_gpus = lib.device_count()
+    if n_gpus < 1:
+        raise RuntimeError('no AMD GPU visible: this engine has no CPU path')
+    devices = [d if d >= 0 else 0 for d in args.devices]
+    print('Initializing %s on device(s) %s.' % (args.weights, devices))
+    weights = load_weights(args.weights, net)
+    farm = TileFarm(net, devices, weights)
+    transfer = StyleTransfer(farm, args, state)
+    content_image = Image.open(args.content_image).convert('RGB')
+    style_images = [Image.open(p).convert('RGB') for p in args.style_images]
+    initial_image = Image.open(args.init_image).convert('RGB') if args.init_image else None
+    aux_image = Image.open(args.aux_image).convert('RGB') if args.aux_image else None
+    stats = StatLogger()
+    progress = Progress(run, stats, args.save_every)
+    np.random.seed(args.seed)
+    try:
+        transfer.transfer_multiscale([content_image], style_images, initial_image, aux_image,
+                                     callback=progress)
+    except (EOFError, KeyboardInterrupt):
+        print()
+    finally:
+        stats.dump(run + '_log.csv')
+    output = transfer.current_output
+    if output is not None:
+        path = args.output_image or run + '_out.png'
+        print('Saving output as %s.' % path)
+        info = PngImagePlugin.PngInfo()
+        info.add_itxt('Comment', image_comment(args, argv))
+        output.save(path, pnginfo=info)
+    spent = time.perf_counter() - start_time
+    steps_time = sum(transfer.step_times)
+    if steps_time > 0:
+        print('%d tile-iterations in %.3f s of stepping: %.2f tile-iterations/s.' %
+              (farm.tile_evals, steps_time, farm.tile_evals / steps_time))
+    print('Run %s ending after %dm %.3fs.' % (run, spent // 60, spent % 60))
+    farm.close()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

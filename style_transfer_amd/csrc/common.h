@@ -135,8 +135,8 @@ int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int
                         float p_power, const float *aux, float aux_scale, double *loss_terms /*[3]*/,
                         float *scratch, size_t scratch_floats);
 int adam_launch(hipStream_t s, float *params, const float *grad, float *g1, float *g2, float *p1,
-                float *avg, size_t n, float lr, float b1, float b2, float bp1, float c1, float c2,
-                float cp);
+                float *avg, size_t n, double lr, double b1, double b2, double bp1, double c1,
+                double c2, double cp);
 int dot_launch(hipStream_t s, const float *x, const float *y, size_t n, double *out_dev,
                float *scratch, size_t scratch_floats);
 int abs_sum_launch(hipStream_t s, const float *x, size_t n, double *out_dev, float *scratch,

@@ -943,8 +943,8 @@ int stx_adam_step(stx_engine *e, float *params, const float *grad, float *g1, fl
                   double corr2, double corrp) {
     if (!e || !params || !grad || !g1 || !g2 || !p1 || !avg_out) return STX_ERR_ARG;
     STX_TRY(e->set_device());
-    return adam_launch(e->stream, params, grad, g1, g2, p1, avg_out, n, (float)lr, (float)b1,
-                       (float)b2, (float)bp1, (float)corr1, (float)corr2, (float)corrp);
+    return adam_launch(e->stream, params, grad, g1, g2, p1, avg_out, n, lr, b1, b2, bp1, corr1,
+                       corr2, corrp);
 }
 
 static int sync_scalar(stx_engine *e, size_t di, int n, double *out) {

@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params,
 }
 
 int adam_launch(hipStream_t s, float *params, const float *grad, float *g1, float *g2, float *p1,
-                float *avg, size_t n, float lr, float b1, float b2, float bp1, float c1, float c2,
-                float cp) {
-    // (1 - beta) is formed in double like the reference's Python scalar, then cast to float32
+                float *avg, size_t n, double lr, double b1, double b2, double bp1, double c1,
+                double c2, double cp) {
+    // every scalar is formed in double like the reference's Python floats and rounded to float32
+    // once, exactly where numpy casts it (beta, 1 - beta, 1 - beta^t, -lr)
     adam_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(
-        params, grad, g1, g2, p1, avg, n, lr, b1, b2, bp1, (float)(1.0 - (double)b1),
-        (float)(1.0 - (double)b2), (float)(1.0 - (double)bp1), c1, c2, cp);
+        params, grad, g1, g2, p1, avg, n, (float)lr, (float)b1, (float)b2, (float)bp1,
+        (float)(1.0 - b1), (float)(1.0 - b2), (float)(1.0 - bp1), (float)c1, (float)c2, (float)cp);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }

@@ -1,0 +1,193 @@
+"""The tile farm: cut the image into tiles, evaluate them on the GPUs, stitch the results.
+
+Replaces ``TileWorkerPool`` + ``CaffeModel.eval_features_once / prepare_features /
+eval_sc_grad`` (``style_transfer.py:267-337,429-486,614-645``).  The reference forks one process
+per device and ships tiles through multiprocessing queues and POSIX shared memory; here ONE
+host process drives one ``TileEngine`` per GPU.  Engines only enqueue kernels, so issuing tile
+t to engine t mod n (the reference's round-robin, ``style_transfer.py:284-288``) and then
+synchronising all engines runs the tiles concurrently.  Tiles are independent -- tile-local
+Gram, zero padding at tile borders, disjoint gradient stitch -- so there is no collective:
+the only traffic is the tile itself (device-to-device over xGMI when the engine is not the
+master GPU) and, once per scale, the targets.
+
+The image lives un-rolled on the master engine; the seam-suppression shift of an iteration is
+passed down as ``roll`` and applied as an index offset when tiles are cut and put back.
+"""
+
+import numpy as np
+
+from . import image_ops
+from .engine import TileEngine
+
+
+def tile_grid(img_hw, tile_size):
+    """[(y0, y1, x0, x1)] in the reference's request order (style_transfer.py:431-451,619-632):
+    n = (size - 1) // tile + 1 tiles per axis of size // n; the last row / column absorbs the
+    remainder."""
+    h, w = int(img_hw[0]), int(img_hw[1])
+    ny, nx = (h - 1) // tile_size + 1, (w - 1) // tile_size + 1
+    th, tw = h // ny, w // nx
+    rects = []
+    for y in range(ny):
+        for x in range(nx):
+            y0, x0 = y * th, x * tw
+            rects.append((y0, h if y == ny - 1 else y0 + th, x0, w if x == nx - 1 else x0 + tw))
+    return rects
+
+
+class TileFarm:
+    """One host process, one engine per entry of ``devices`` (the reference's ``--devices``)."""
+
+    def __init__(self, net, devices=(0,), weights=None, verbose=True):
+        self.net = net
+        self.verbose = verbose
+        self.engines = [TileEngine(net, d, weights) for d in devices]
+        self.master = self.engines[0]
+        self._tiles = {}        # (engine index, slot, th, tw) -> (tile DeviceArray, grad DeviceArray)
+        self._staging = {}      # (slot, th, tw) -> master-side staging for remote engines
+        self.tile_evals = 0     # tile-iterations executed (the benchmark's unit of work)
+
+    def close(self):
+        for bufs in list(self._tiles.values()) + list(self._staging.values()):
+            for b in bufs:
+                b.free()
+        self._tiles.clear()
+        self._staging.clear()
+        for e in self.engines:
+            e.close()
+
+    def layers(self):
+        return self.net.blob_names()
+
+    def layer_info(self, layer):
+        return self.net.layer_info(layer)
+
+    def set_weights(self, weights):
+        for e in self.engines:
+            for name, (w, b) in weights.items():
+                e.set_weights(name, w, b)
+
+    def set_contents_and_styles(self, contents, styles):
+        """Hands the targets to every engine (TileWorkerPool.set_contents_and_styles,
+        style_transfer.py:309-332)."""
+        for e in self.engines:
+            e.set_contents_and_styles(contents, styles)
+
+    # ------------------------------------------------------------------ eval_features_once
+    def eval_features_once(self, img, layers, tile_size=512):
+        """Stitched post-ReLU feature maps {layer: [C, ceil(H/s), ceil(W/s)]} of a host image
+        [3,H,W] (style_transfer.py:429-464)."""
+        img = np.ascontiguousarray(img, np.float32)
+        hw = np.array(img.shape[-2:])
+        rects = tile_grid(hw, tile_size)
+        if len(rects) > 1 and self.verbose:
+            nx = (hw[1] - 1) // tile_size + 1
+            print('Using %dx%d tiles of size %dx%d.' %
+                  (nx, len(rects) // nx, rects[0][3] - rects[0][2], rects[0][1] - rects[0][0]))
+        feats = {}
+        for layer in layers:
+            scale, ch = self.layer_info(layer)
+            feats[layer] = np.zeros((ch,) + tuple(np.int32(np.ceil(hw / scale))), np.float32)
+        for t, (y0, y1, x0, x1) in enumerate(rects):
+            eng = self.engines[t % len(self.engines)]
+            tile_feats = eng.features_tile(img[:, y0:y1, x0:x1], list(layers))
+            for layer, f in tile_feats.items():
+                scale, _ = self.layer_info(layer)
+                fy, fx = y0 // scale, x0 // scale
+                feats[layer][:, fy:fy + f.shape[1], fx:fx + f.shape[2]] = f
+        return feats
+
+    # -------------------------------------------------------------------- prepare_features
+    def prepare_features(self, img, layers, tile_size=512, passes=10):
+        """Feature maps averaged over randomly rolled tilings to hide the tile seams
+        (style_transfer.py:466-486).  Draws from the global numpy RNG like the reference."""
+        img = np.array(img, np.float32)
+        hw = np.array(img.shape[-2:])
+        if max(hw) <= tile_size:
+            passes = 1
+        feats = {}
+        for i in range(passes):
+            xy = np.array((0, 0))
+            if i > 0:
+                xy = np.int32(np.random.uniform(size=2) * hw) // 32
+            self._roll_host(img, xy * 32)
+            for layer, f in feats.items():
+                self._roll_host(f, xy * 32 // self.layer_info(layer)[0])
+            once = self.eval_features_once(img, layers, tile_size)
+            for layer in layers:
+                if i == 0:
+                    feats[layer] = once[layer] / passes
+                else:
+                    feats[layer] += np.float32(1 / passes) * once[layer]
+            self._roll_host(img, -xy * 32)
+            for layer, f in feats.items():
+                self._roll_host(f, -xy * 32 // self.layer_info(layer)[0])
+        return feats
+
+    @staticmethod
+    def _roll_host(arr, xy):
+        """roll2 (num_utils.py:136-140): xy[0] shifts the last axis, xy[1] the one before."""
+        if np.any(np.asarray(xy) != 0):
+            arr[...] = np.roll(arr, (int(xy[0]), int(xy[1])), axis=(-1, -2))
+        return arr
+
+    def gram_matrix(self, feat):
+        return self.master.gram_matrix(feat)
+
+    # ------------------------------------------------------------------------ eval_sc_grad
+    def _tile_buffers(self, ei, slot, th, tw):
+        key = (ei, slot, th, tw)
+        if key not in self._tiles:
+            eng = self.engines[ei]
+            self._tiles[key] = (eng.empty((3, th, tw)), eng.empty((3, th, tw)))
+        return self._tiles[key]
+
+    def _staging_buffers(self, slot, th, tw):
+        key = (slot, th, tw)
+        if key not in self._staging:
+            self._staging[key] = (self.master.empty((3, th, tw)), self.master.empty((3, th, tw)))
+        return self._staging[key]
+
+    def eval_sc_grad(self, img, grad, roll, content_layers, style_layers, layer_weights,
+                     content_weight, style_weight, tile_size):
+        """Summed loss and stitched gradient of all tiles (style_transfer.py:614-645).
+
+        img, grad: DeviceArray [3,H,W] on the master GPU, both in the UN-rolled frame; ``roll`` is
+        the current iteration's shift in pixels (what the reference passes as the request's
+        ``roll`` after physically rolling the image by it).  Returns the loss."""
+        n = len(self.engines)
+        rects = tile_grid(img.shape[-2:], tile_size)
+        jobs = []
+        remote = False
+        for t, rect in enumerate(rects):
+            ei, slot = t % n, t // n
+            th, tw = rect[1] - rect[0], rect[3] - rect[2]
+            tile, tgrad = self._tile_buffers(ei, slot, th, tw)
+            if ei == 0:
+                image_ops.cut_tile(self.master, img, roll, rect, tile)
+                stage = None
+            else:
+                stage = self._staging_buffers(t, th, tw)
+                image_ops.cut_tile(self.master, img, roll, rect, stage[0])
+                remote = True
+            jobs.append((ei, rect, tile, tgrad, stage))
+        if remote:
+            self.master.sync()      # staged tiles are complete before other GPUs pull them
+        pending = []
+        for ei, rect, tile, tgrad, stage in jobs:
+            eng = self.engines[ei]
+            if stage is not None:
+                tile.copy_from(stage[0])            # peer copy on the worker's stream
+            pending.append(eng.sc_grad_tile_async(
+                tile, (rect[0], rect[2]), roll, content_layers, style_layers, layer_weights,
+                content_weight, style_weight, grad_out=tgrad))
+        for eng in self.engines[1:]:
+            eng.sync()
+        for (ei, rect, tile, tgrad, stage) in jobs:
+            if stage is not None:
+                stage[1].copy_from(tgrad)           # peer copy on the master's stream
+                tgrad = stage[1]
+            image_ops.put_tile(self.master, grad, roll, rect, tgrad)
+        self.master.sync()
+        self.tile_evals += len(rects)
+        return sum(p.loss for p in pending)

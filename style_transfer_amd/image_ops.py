@@ -1,0 +1,102 @@
+"""Device-resident full-image operations (thin wrappers over the stx_image_* / stx_vec_* ABI).
+
+These replace the host-side numpy of the reference's step loop: ``roll2`` + tile slicing
+(``num_utils.py:136-140``, ``style_transfer.py:632,642``), ``tv_norm`` / ``p_norm`` / aux term
+(``style_transfer.py:709-733``), the statistics of ``transfer`` (``style_transfer.py:808-815``)
+and ``get_image`` (``style_transfer.py:378-386``).  Images are ``DeviceArray`` [3,H,W] on the
+engine's GPU and stay UN-rolled: the per-iteration shift is an index offset in cut / put.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import lib
+
+
+def _xy(roll):
+    if roll is None:
+        return (ctypes.c_int * 2)(0, 0)
+    return (ctypes.c_int * 2)(int(roll[0]), int(roll[1]))
+
+
+def cut_tile(engine, img, roll_xy, rect, tile):
+    """tile <- window rect=(y0,y1,x0,x1) of roll2(img, roll_xy)."""
+    y0, y1, x0, x1 = rect
+    _, H, W = img.shape
+    lib.call('stx_image_cut_tile', engine.handle, img.ptr, H, W, _xy(roll_xy), y0, x0, y1 - y0,
+             x1 - x0, tile.ptr)
+
+
+def put_tile(engine, grad, roll_xy, rect, tile_grad):
+    """Places a tile gradient back into the un-rolled full gradient."""
+    y0, y1, x0, x1 = rect
+    _, H, W = grad.shape
+    lib.call('stx_image_put_tile', engine.handle, grad.ptr, H, W, _xy(roll_xy), y0, x0, y1 - y0,
+             x1 - x0, tile_grad.ptr)
+
+
+class PendingScalar:
+    def __init__(self):
+        self._v = ctypes.c_double(float('nan'))
+
+    @property
+    def value(self):
+        return self._v.value
+
+
+def regularizers(engine, img, grad, mean_bgr, tv_scale, tv_power, p_scale, p_power, aux=None,
+                 aux_scale=0.0):
+    """grad += regularizer gradients; returns a PendingScalar with the loss (valid after sync)."""
+    _, H, W = img.shape
+    mean = (ctypes.c_float * 3)(*[float(m) for m in np.ravel(mean_bgr)])
+    out = PendingScalar()
+    lib.call('stx_image_regularizers', engine.handle, img.ptr, grad.ptr, H, W, mean,
+             float(tv_scale), float(tv_power), float(p_scale), float(p_power),
+             aux.ptr if aux is not None else None, float(aux_scale), ctypes.byref(out._v))
+    return out
+
+
+def adam_step(engine, params, grad, g1, g2, p1, avg, lr, b1, b2, bp1, corr1, corr2, corrp):
+    lib.call('stx_adam_step', engine.handle, params.ptr, grad.ptr, g1.ptr, g2.ptr, p1.ptr, avg.ptr,
+             params.size, float(lr), float(b1), float(b2), float(bp1), float(corr1), float(corr2),
+             float(corrp))
+
+
+def dot(engine, x, y):
+    out = ctypes.c_double(0)
+    lib.call('stx_vec_dot', engine.handle, x.ptr, y.ptr, x.size, ctypes.byref(out))
+    return out.value
+
+
+def mean_abs(engine, x):
+    out = ctypes.c_double(0)
+    lib.call('stx_vec_mean_abs', engine.handle, x.ptr, x.size, ctypes.byref(out))
+    return out.value
+
+
+def axpy(engine, a, x, y):
+    lib.call('stx_vec_axpy', engine.handle, float(a), x.ptr, y.ptr, x.size)
+
+
+def scale(engine, a, x):
+    lib.call('stx_vec_scale', engine.handle, float(a), x.ptr, x.size)
+
+
+def step_stats(engine, avg, old):
+    """(mean|avg-old|, sqrt(mean(xdiff^2+ydiff^2))); old <- avg."""
+    _, H, W = avg.shape
+    out = (ctypes.c_double * 2)()
+    lib.call('stx_image_step_stats', engine.handle, avg.ptr, old.ptr, H, W, out)
+    return out[0], out[1]
+
+
+def to_u8(engine, img, mean_bgr):
+    """RGB HWC uint8 ndarray of img + mean, clipped and truncated like the reference."""
+    _, H, W = img.shape
+    mean = (ctypes.c_float * 3)(*[float(m) for m in np.ravel(mean_bgr)])
+    out = engine.empty((H, W, 3), np.uint8)
+    lib.call('stx_image_to_u8', engine.handle, img.ptr, H, W, mean, out.ptr)
+    host = out.get()
+    out.free()
+    return host

@@ -1,0 +1,48 @@
+"""The whole multi-scale schedule on the GPU against the run the reference's own
+``transfer_multiscale`` produced (tests/golden: 2 scales, 2x2 tiles, 3+2 Adam steps, seed 5).
+
+Per-step losses must agree to 1e-4 relative.  The final averaged image is compared per pixel
+with an absolute tolerance of 0.5 (on a 0..255 scale): five normalised-gradient steps amplify
+the few max-pool / ReLU decision flips discussed in test_gpu_tile_path.py."""
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from style_transfer_amd.config_system import parse_args
+from style_transfer_amd.farm import TileFarm
+from style_transfer_amd.netspec import builtin_net
+from style_transfer_amd.transfer import StyleTransfer
+from style_transfer_amd.weights import synthetic_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_transfer_multiscale_matches_reference_run(golden):
+    from argparse import Namespace
+    argv = str(golden['e2e.argv']).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net('vgg19')
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e.content_u8'])],
+                           [Image.fromarray(golden['e2e.style_u8'])],
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    ref = golden['e2e.log']
+    got = np.float64(log)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-4), (got[:, 2], ref[:, 2])     # loss
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-3)                             # update size
+    assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-3)                             # tv statistic
+    final = st.current_raw.get()
+    assert final.shape == golden['e2e.final_raw'].shape
+    assert np.abs(final - golden['e2e.final_raw']).max() < 0.5
+    u8 = np.asarray(st.current_output)
+    assert np.abs(u8.astype(int) - golden['e2e.final_u8'].astype(int)).max() <= 1
+    assert farm.tile_evals == 4 * 3 + 4 * 2
+    farm.close()

@@ -1,0 +1,135 @@
+"""Full-image kernels (regularizers, Adam, L-BFGS algebra, cut/put, statistics, uint8) against
+vectors produced by the reference's num_utils / optimizers and against the oracle."""
+
+import numpy as np
+import pytest
+
+from oracle import num_ops
+from oracle.tile_path import regularizer_loss_grad
+from style_transfer_amd import image_ops
+from style_transfer_amd.optimizers import AdamOptimizer, LBFGSOptimizer
+from tests.gpu_helpers import gpu_engine, max_rel
+
+pytestmark = pytest.mark.gpu
+MEAN = np.float32((103.939, 116.779, 123.68)).reshape(3, 1, 1)
+
+
+@pytest.mark.parametrize('beta', [2, 1.5])
+def test_tv_and_pnorm_match_reference_vectors(golden, beta):
+    eng = gpu_engine()
+    img = golden['num.img']
+    d_img, d_grad = eng.to_device(img), eng.empty(img.shape).zero()
+    # tv_norm(img/127.5, beta) alone, scale 1
+    res = image_ops.regularizers(eng, d_img, d_grad, MEAN, 1.0, beta, 0.0, 6.0)
+    eng.sync()
+    assert res.value == pytest.approx(float(golden['num.tv_loss_%g' % beta]), rel=2e-6)
+    assert max_rel(d_grad.get(), golden['num.tv_grad_%g' % beta]) < 2e-6
+    # p_norm(x/127.5, 6): feed mean = 127.5 so that (img + mean - 127.5)/127.5 == img/127.5
+    d_grad.zero()
+    res = image_ops.regularizers(eng, d_img, d_grad, np.float32([127.5] * 3), 0.0, 2.0, 1.0, 6.0)
+    eng.sync()
+    assert res.value == pytest.approx(float(golden['num.p6_loss']), rel=2e-6)
+    assert max_rel(d_grad.get(), golden['num.p6_grad']) < 2e-6
+
+
+def test_regularizers_with_aux_against_oracle():
+    eng = gpu_engine()
+    rng = np.random.RandomState(4)
+    img = rng.uniform(-120, 130, (3, 45, 67)).astype(np.float32)
+    aux = rng.uniform(-120, 130, (3, 45, 67)).astype(np.float32)
+    g0 = rng.standard_normal(img.shape).astype(np.float32)
+    ref = g0.copy()
+    ref_loss = regularizer_loss_grad(img, MEAN, ref, 0.7, 5.0, 1.5, 2.0, 6.0, aux, 10.0)
+    d_grad = eng.to_device(g0)
+    res = image_ops.regularizers(eng, eng.to_device(img), d_grad, MEAN, 0.7 * 5.0, 1.5, 0.7 * 2.0,
+                                 6.0, eng.to_device(aux), 0.7 * 10.0)
+    eng.sync()
+    assert res.value == pytest.approx(ref_loss, rel=1e-5)
+    assert max_rel(d_grad.get(), ref) < 1e-5
+
+
+def test_cut_and_put_tile_are_roll_then_slice():
+    eng = gpu_engine()
+    rng = np.random.RandomState(5)
+    img = rng.standard_normal((3, 37, 52)).astype(np.float32)
+    d_img = eng.to_device(img)
+    for roll in [(0, 0), (8, -16), (-51, 36), (104, -74)]:
+        rolled = num_ops.roll_xy(img.copy(), roll)
+        rect = (5, 30, 11, 49)
+        tile = eng.empty((3, 25, 38))
+        image_ops.cut_tile(eng, d_img, roll, rect, tile)
+        assert np.array_equal(tile.get(), rolled[:, 5:30, 11:49])
+        # put: writing the tile of a rolled gradient back un-rolls it
+        full = eng.empty(img.shape).zero()
+        image_ops.put_tile(eng, full, roll, rect, tile)
+        expect = np.zeros_like(img)
+        expect[:, 5:30, 11:49] = rolled[:, 5:30, 11:49]
+        assert np.array_equal(full.get(), num_ops.roll_xy(expect, (-roll[0], -roll[1])))
+
+
+def _quad(eng, target_dev):
+    diff = eng.empty(target_dev.shape)
+
+    def f(x):
+        diff.copy_from(x)
+        image_ops.axpy(eng, -1.0, target_dev, diff)
+        loss = image_ops.dot(eng, diff, diff)
+        image_ops.scale(eng, 2.0, diff)
+        return loss, diff
+    return f
+
+
+@pytest.mark.parametrize('biased', [0, 1])
+def test_adam_matches_reference_trajectory(golden, biased):
+    """optimizers.AdamOptimizer incl. roll / un-roll (no-ops on un-rolled device state)."""
+    eng = gpu_engine()
+    params = eng.to_device(golden['opt.x0'])
+    opt = AdamOptimizer(eng, params, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5,
+                        biased_g1=bool(biased))
+    f = _quad(eng, eng.to_device(golden['opt.target']))
+    for i, xy in enumerate(golden['opt.rolls']):
+        opt.roll(xy)
+        avg, loss = opt.update(f)
+        opt.roll(-xy)
+        # 5e-6: BLAS saxpy may fuse a*x+y, the kernel rounds the product first
+        assert max_rel(avg.get(), golden['opt.adam_biased%d.avg' % biased][i]) < 5e-6
+        assert loss == pytest.approx(golden['opt.adam_biased%d.loss' % biased][i], rel=1e-5)
+    assert max_rel(params.get(), golden['opt.adam_biased%d.params' % biased]) < 5e-6
+
+
+def test_lbfgs_matches_reference_trajectory(golden):
+    eng = gpu_engine()
+    params = eng.to_device(golden['opt.x0'])
+    tgt = eng.to_device(golden['opt.target'])
+    scale = golden['opt.lbfgs.scale']
+    d_scale = eng.to_device(scale)
+    work = eng.empty(params.shape)
+
+    def f(x):
+        # d = (x - t) * s ; loss = sum d^2 ; grad = 2 d s   (host multiply keeps the test simple)
+        d = (x.get() - golden['opt.target']) * scale
+        work.set((2 * d * scale).astype(np.float32))
+        return float(np.sum(d * d, dtype=np.float64)), work
+    opt = LBFGSOptimizer(eng, params)
+    for i in range(len(golden['opt.lbfgs.loss'])):
+        p, loss = opt.update(f)
+        assert max_rel(p.get(), golden['opt.lbfgs.params'][i]) < 5e-4
+        assert loss == pytest.approx(golden['opt.lbfgs.loss'][i], rel=5e-3, abs=1e-3)
+    del tgt, d_scale
+
+
+def test_step_stats_and_uint8():
+    eng = gpu_engine()
+    rng = np.random.RandomState(6)
+    avg = rng.uniform(-140, 160, (3, 33, 41)).astype(np.float32)
+    old = rng.uniform(-140, 160, (3, 33, 41)).astype(np.float32)
+    d_avg, d_old = eng.to_device(avg), eng.to_device(old)
+    upd, tv = image_ops.step_stats(eng, d_avg, d_old)
+    xd = avg - np.roll(avg, -1, axis=-1)
+    yd = avg - np.roll(avg, -1, axis=-2)
+    assert upd == pytest.approx(float(np.mean(abs(avg - old))), rel=1e-5)
+    assert tv == pytest.approx(float(np.sqrt(np.mean(xd ** 2 + yd ** 2))), rel=1e-5)
+    assert np.array_equal(d_old.get(), avg)
+    u8 = image_ops.to_u8(eng, d_avg, MEAN)
+    ref = np.uint8(np.clip((avg + MEAN)[::-1].transpose(1, 2, 0), 0, 255))
+    assert np.array_equal(u8, ref)
