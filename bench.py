@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tile-iterations/s of the tiled style-transfer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one optimizer iteration of the reference's step loop (style_transfer.py:771-806) at the
+top scale of BASELINE.json's config 2 ("VGG-19 --size 1024 --tile-size 1024, Adam"): draw the
+seam-suppression shift, cut the tile(s), per-tile VGG-19 forward + Gram/content losses + backward
+(stx_sc_grad_tile), stitch, TV + p-norm regularizers, fused Adam step with iterate averaging, step
+statistics.  Everything is resident in HBM when the timed region starts.  Synthetic data: seeded
+He-initialised VGG-19 weights, seeded low-pass-noise content and style pictures (no network).
+
+N > 1 is weak scaling: every rank evaluates one 1024 x 1024 tile per step, the image is a grid of
+N such tiles on rank 0 (2048 x 2048 / 1024-px tiles at N = 4 is BASELINE.json's headline config 3);
+tiles go out and gradients come back point-to-point over RCCL, there is no collective on the data
+path.  value = tile-iterations per second of the whole job.
+
+The line also carries
+  roofline      algorithmic FLOP of one tile-iteration (1 514 240 FLOP per
+                tile pixel) over the GPU time of one stx_sc_grad_tile call, measured with HIP
+                events on the engine's stream inside the timed region, against the fp32 MFMA peak;
+  cpu_baseline  the numpy oracle (a port of the reference's Caffe-CPU path) timed on this box's
+                host cores on a bounded sample -- rank 0, N = 1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+TILE = 1024
+FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+CONTENT_LAYERS = ['conv4_2']
+STYLE_LAYERS = ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+MEAN = (103.939, 116.779, 123.68)
+
+
+def smooth_picture(seed, h, w):
+    """Low-pass filtered seeded noise, float32 BGR minus mean, [3,h,w]."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    small = rng.uniform(0, 255, (max(2, h // 16), max(2, w // 16), 3)).astype(np.uint8)
+    big = np.asarray(Image.fromarray(small).resize((w, h), Image.BICUBIC), np.float32)
+    big = np.clip(big + rng.uniform(-16, 16, big.shape), 0, 255)
+    return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
+
+
+def cpu_baseline(net):
+    """Times the oracle's tile evaluation on the host cores (checker used as a yardstick only)."""
+    from oracle.caffe_net import synthetic_weights
+    from oracle.tile_path import OracleModel
+    size = 512
+    layers = net.as_dicts()
+    om = OracleModel(layers, synthetic_weights(layers, 0))
+    rng = np.random.RandomState(1)
+    tile = smooth_picture(2, size, size)
+    cw = {'conv4_2': 0.05}
+    sw = {l: 0.2 for l in STYLE_LAYERS}
+    om.contents = [{'conv4_2': np.abs(rng.standard_normal((512, size // 8, size // 8))).astype(np.float32)}]
+    om.styles = [{l: np.tril(rng.standard_normal((om.channels[l],) * 2)).astype(np.float32)
+                  for l in STYLE_LAYERS}]
+    om.sc_grad_tile(tile[:, :128, :128], (0, 0), CONTENT_LAYERS, STYLE_LAYERS, {}, cw, sw)  # warm
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 10 and reps < 8):
+        om.sc_grad_tile(tile, (0, 0), CONTENT_LAYERS, STYLE_LAYERS, {}, cw, sw)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    return {'value': 1.0 / (dt * (TILE * TILE) / (size * size)), 'unit': 'tile-iterations/s',
+            'cores': cores, 'kind': 'port',
+            'sample': '%d VGG-19 tile-iterations at %dx%d with the numpy oracle (im2col + '
+                      'multithreaded SGEMM, %.2f s each), scaled by pixel count to the '
+                      '%dx%d benchmark tile' % (reps, size, size, dt, TILE, TILE)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    opts = ap.parse_args()
+
+    import torch                                       # first: one HIP runtime for both libraries
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != opts.gpus:
+        if world == 1 and opts.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
+                     '(one process per GPU)' % opts.gpus)
+        sys.exit('WORLD_SIZE=%d does not match --gpus %d' % (world, opts.gpus))
+    if opts.gpus not in GRIDS:
+        sys.exit('--gpus must be one of %s' % sorted(GRIDS))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an AMD GPU (no CPU path exists)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from style_transfer_amd import image_ops, lib
+    from style_transfer_amd.engine import TileEngine
+    from style_transfer_amd.farm import tile_grid
+    from style_transfer_amd.netspec import builtin_net
+    from style_transfer_amd.optimizers import AdamOptimizer
+    from style_transfer_amd.weights import synthetic_weights
+
+    net = builtin_net('vgg19')
+    eng = TileEngine(net, local_rank, synthetic_weights(net, 0))
+    rows, cols = GRIDS[world]
+    H, W = rows * TILE, cols * TILE
+    rects = tile_grid((H, W), TILE)
+    content_weight = {'conv4_2': 0.05}
+    style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
+
+    # ---- targets (once, outside the timed region): style Grams and the content map of the image
+    contents, styles = [], []
+    if rank == 0:
+        from style_transfer_amd.farm import TileFarm
+        helper = TileFarm(net, verbose=False, engines=[eng])
+        style_feats = helper.eval_features_once(smooth_picture(7, TILE, TILE), STYLE_LAYERS, TILE)
+        styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
+        contents = [helper.eval_features_once(smooth_picture(8, H, W), CONTENT_LAYERS, TILE)]
+    if world > 1:
+        from style_transfer_amd.dist import DistributedTiles, broadcast_targets
+        contents, styles = broadcast_targets(contents, styles, device)
+    eng.set_contents_and_styles(contents, styles)
+
+    def wrap(tensor):
+        """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
+        from style_transfer_amd.engine import DeviceArray
+        arr = DeviceArray.__new__(DeviceArray)
+        arr.engine, arr.shape, arr.dtype = eng, tuple(tensor.shape), np.dtype(np.float32)
+        arr.nbytes, arr.ptr = tensor.numel() * 4, tensor.data_ptr()
+        arr.free = lambda: None
+        return arr
+
+    tile_ms = []
+    state = {}
+    if rank == 0:
+        rng = np.random.RandomState(0)
+        # the reference's start image: uniform noise minus the mean (style_transfer.py:889)
+        img = eng.to_device(rng.uniform(0, 255, (3, H, W)).astype(np.float32) -
+                            np.float32(MEAN).reshape(3, 1, 1))
+        grad = eng.empty((3, H, W))
+        old_avg = eng.empty((3, H, W)).copy_from(img)
+        opt = AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
+        state.update(img=img, grad=grad, old=old_avg, opt=opt, rng=np.random.RandomState(0))
+
+    if world == 1:
+        tile_buf, tgrad_buf = eng.empty((3, TILE, TILE)), eng.empty((3, TILE, TILE))
+
+        def eval_sc_grad(params, roll):
+            image_ops.cut_tile(eng, params, roll, rects[0], tile_buf)
+            pend = eng.sc_grad_tile_async(tile_buf, (0, 0), roll, CONTENT_LAYERS, STYLE_LAYERS, {},
+                                          content_weight, style_weight, grad_out=tgrad_buf)
+            image_ops.put_tile(eng, state['grad'], roll, rects[0], tgrad_buf)
+            return pend
+    else:
+        send_bufs = {}
+
+        def cut(rect, roll):
+            key = rect
+            if key not in send_bufs:
+                send_bufs[key] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
+                                             dtype=torch.float32, device=device)
+            image_ops.cut_tile(eng, state['img'], roll, rect, wrap(send_bufs[key]))
+            eng.sync()
+            return send_bufs[key]
+
+        grad_t = torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
+
+        def evaluate(tile, start, roll):
+            pend = eng.sc_grad_tile_async(wrap(tile), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {},
+                                          content_weight, style_weight, grad_out=wrap(grad_t))
+            eng.sync()
+            tile_ms.append(eng.last_tile_ms())
+            return pend.loss, grad_t
+
+        def put(rect, g, roll):
+            image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g))
+
+        farm = DistributedTiles(cut, evaluate, put, device)
+
+    def step():
+        if rank == 0:
+            xy = np.int32(state['rng'].uniform(-0.5, 0.5, size=2) * (H, W)) // 8
+            roll = xy * 8
+        else:
+            roll = (0, 0)
+
+        def opfunc(params):
+            if world == 1:
+                pend = eval_sc_grad(params, roll)
+                reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
+                eng.sync()
+                tile_ms.append(eng.last_tile_ms())
+                return pend.loss + reg.value, state['grad']
+            loss = farm.eval_sc_grad(rects, roll)
+            reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
+            eng.sync()
+            return loss + reg.value, state['grad']
+
+        if rank == 0:
+            avg, loss = state['opt'].update(opfunc)
+            image_ops.step_stats(eng, avg, state['old'])
+            return loss
+        farm.eval_sc_grad(rects, roll)
+        return None
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(opts.warmup):
+        step()
+    fence()
+    tile_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(opts.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        ms_per_step = elapsed / opts.steps * 1e3
+        tiles_per_step = len(rects)
+        tile_avg_ms = float(np.mean(tile_ms))
+        flop = FLOP_PER_TILE_PIXEL * TILE * TILE
+        achieved = flop / (tile_avg_ms * 1e-3) / 1e12
+        line = {
+            'metric': 'tile-iterations/sec, VGG-19 1024px tiles (fwd+bwd, Gram/content losses, '
+                      'regularizers, Adam step)',
+            'value': tiles_per_step * opts.steps / elapsed,
+            'unit': 'tile-iterations/s',
+            'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tile(s) '
+                                   'of %dx%d per step, one per GPU' % (max(H, W), TILE, W, H,
+                                                                      tiles_per_step, TILE, TILE),
+                       'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
+                       'tiles_per_step': tiles_per_step, 'final_loss': loss},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         'traffic': None,
+                         'kernel': 'stx_sc_grad_tile (conv_mfma_kernel fwd/dgrad/SYMM + gram)',
+                         'flop_per_launch': flop, 'avg_launch_ms': tile_avg_ms},
+        }
+        if world == 1 and not opts.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(net)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -223,6 +223,14 @@ int stx_op_pool_forward(stx_engine *e, const float *x, int C, int H, int W, int 
 int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, int H, int W,
                          int mode, const float *relu_mask_data, float *dx);
 
+/* Per-kernel-group timing for tuning and for bench.py's roofline figures: while enabled, every
+ * launch group of the tile path (one conv / pool / Gram / SYMM / injection) is bracketed by HIP
+ * events on the engine stream.  stx_profile_read synchronises, writes one line per group
+ * "label<TAB>milliseconds<TAB>algorithmic_flops" into buf (NUL-terminated, truncated to buf_len;
+ * *needed receives the full size) and clears the record. */
+int stx_profile_enable(stx_engine *e, int on);
+int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed);
+
 /* Timing: ms spent by the GPU between the first and last kernel of the most recent
  * stx_sc_grad_tile / stx_features_tile on this engine (HIP events on the engine stream);
  * valid after stx_sync. */

@@ -131,6 +131,16 @@ struct stx_engine {
     DevBuf red_scratch;                // float partials for image-op reductions
     std::vector<PendingLoss> pending;
 
+    // optional per-kernel-group timing (stx_profile_enable): event pairs around launch groups
+    bool profiling = false;
+    struct ProfEntry {
+        std::string label;
+        double flops;
+        hipEvent_t start, stop;
+    };
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+
     int set_device() {
         STX_HIP(hipSetDevice(device));
         return STX_OK;
@@ -145,6 +155,38 @@ struct stx_engine {
 namespace {
 
 constexpr size_t kScalarFloats = 1 << 16;   // per-call scalar arena (sums + small partials)
+
+// RAII timing of one launch group when profiling is on (no-op otherwise).
+struct ProfScope {
+    stx_engine *e;
+    int index = -1;
+    ProfScope(stx_engine *eng, const std::string &label, double flops) : e(eng) {
+        if (!e->profiling) return;
+        auto take = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!e->event_pool.empty()) {
+                ev = e->event_pool.back();
+                e->event_pool.pop_back();
+            } else if (hipEventCreate(&ev) != hipSuccess) {
+                ev = nullptr;
+            }
+            return ev;
+        };
+        stx_engine::ProfEntry pe{label, flops, take(), take()};
+        if (!pe.start || !pe.stop) return;
+        (void)hipEventRecord(pe.start, e->stream);
+        e->prof.push_back(pe);
+        index = (int)e->prof.size() - 1;
+    }
+    ~ProfScope() {
+        if (index >= 0) (void)hipEventRecord(e->prof[index].stop, e->stream);
+    }
+};
+
+double conv_flops(int K, int M, int H, int W, int ks) {
+    return 2.0 * K * M * ks * ks * (double)H * W;
+}
+
 
 int alloc_scalars(stx_engine *e, size_t n, size_t *index) {
     if (e->scalars_used + n > e->scalars_cap) {
@@ -260,6 +302,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     p.ksize = cp.ks;
     p.relu = (t.relu || force_relu) ? 1 : 0;
     p.epilogue = kEpiForward;
+    ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
 
@@ -282,6 +325,7 @@ int run_conv_backward(stx_engine *e, int li) {
     p.W = b.w;
     p.ksize = cp.ks;
     p.epilogue = kEpiDgrad;
+    ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
 
@@ -296,6 +340,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
         if (L.type == STX_LAYER_CONV) {
             STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob));
         } else {
+            ProfScope scope(e, "fwd " + L.name, 0.0);
             STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
                                         t.data.f()));
             if (t.relu || L.top_blob == relu_blob)
@@ -502,6 +547,11 @@ void stx_engine_destroy(stx_engine *e) {
     for (DevBuf *b : bufs) b->release();
     if (e->scalars_host) (void)hipHostFree(e->scalars_host);
     if (e->dscalars_host) (void)hipHostFree(e->dscalars_host);
+    for (auto &pe : e->prof) {
+        (void)hipEventDestroy(pe.start);
+        (void)hipEventDestroy(pe.stop);
+    }
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -775,8 +825,12 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
                 float *sums = e->scalars.f() + si;
-                STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
+                {
+                    ProfScope scope(e, "content " + b.name, 0.0);
+                    STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
+                }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->content_weight * 0.5});
+                ProfScope scope(e, "inject " + b.name, 0.0);
                 STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), ct.feat->f(), win,
                                               sums, (float)(lw * tp.t->content_weight),
                                               diff_written));
@@ -806,9 +860,12 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
                 float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
-                STX_TRY(gram_partials_launch(e->stream, b.data.f(), plan, e->gram_partials.f()));
-                STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr,
-                                           st.gram->f(), e->dsym.f(), sc));
+                {
+                    ProfScope scope(e, "gram " + b.name, 2.0 * C * C * (double)HW);
+                    STX_TRY(gram_partials_launch(e->stream, b.data.f(), plan, e->gram_partials.f()));
+                    STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr,
+                                               st.gram->f(), e->dsym.f(), sc));
+                }
                 // S = sym(tril(G - Gs)) . F  with sum|S| partials
                 const ConvConfig cfg = conv_pick_config(1, C, C, b.h, b.w);
                 const int n_wg = conv_num_workgroups(cfg, C, b.h, b.w);
@@ -824,9 +881,13 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 p.W = b.w;
                 p.ksize = 1;
                 p.epilogue = kEpiSymm;
-                STX_TRY(conv_launch(e->stream, cfg, p, false));
-                STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+                {
+                    ProfScope scope(e, "symm " + b.name, 2.0 * C * C * (double)HW);
+                    STX_TRY(conv_launch(e->stream, cfg, p, false));
+                    STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+                }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->n_styles});
+                ProfScope scope(e, "inject " + b.name, 0.0);
                 STX_TRY(inject_style_launch(e->stream, b.diff.f(), e->sgrad.f(), b.count(), sc + 1,
                                             nullptr, 0,
                                             (float)(lw * tp.t->style_weight / e->n_styles),
@@ -858,6 +919,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         if (L.type == STX_LAYER_CONV) {
             STX_TRY(run_conv_backward(e, li));
         } else {
+            ProfScope scope(e, "bwd " + L.name, 0.0);
             STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels, bot.h,
                                          bot.w, L.pool_mode, bot.relu, bot.diff.f()));
         }
@@ -1073,6 +1135,43 @@ int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, 
     STX_TRY(e->set_device());
     // the mask source is the pool input itself (post-ReLU data of the blob below)
     return pool_backward_launch(e->stream, dy, x, C, H, W, mode, relu_mask_data != nullptr, dx);
+}
+
+int stx_profile_enable(stx_engine *e, int on) {
+    if (!e) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    STX_HIP(hipStreamSynchronize(e->stream));
+    for (auto &pe : e->prof) {
+        e->event_pool.push_back(pe.start);
+        e->event_pool.push_back(pe.stop);
+    }
+    e->prof.clear();
+    e->profiling = on != 0;
+    return STX_OK;
+}
+
+int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed) {
+    if (!e || (!buf && buf_len)) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    STX_HIP(hipStreamSynchronize(e->stream));
+    std::string out;
+    for (auto &pe : e->prof) {
+        float ms = 0.f;
+        STX_HIP(hipEventElapsedTime(&ms, pe.start, pe.stop));
+        char line[256];
+        snprintf(line, sizeof line, "%s\t%.6f\t%.6e\n", pe.label.c_str(), ms, pe.flops);
+        out += line;
+        e->event_pool.push_back(pe.start);
+        e->event_pool.push_back(pe.stop);
+    }
+    e->prof.clear();
+    if (needed) *needed = out.size() + 1;
+    if (buf_len) {
+        const size_t n = std::min(buf_len - 1, out.size());
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return STX_OK;
 }
 
 int stx_last_tile_ms(stx_engine *e, float *ms) {

@@ -269,6 +269,20 @@ class TileEngine:
         lib.call('stx_gram_matrix', self.handle, ptr, mem, c, hw, out.ctypes.data, lib.HOST)
         return out
 
+    def profile(self, on=True):
+        """Turns per-kernel-group event timing on or off (clears the record)."""
+        lib.call('stx_profile_enable', self.handle, int(on))
+
+    def profile_read(self):
+        """[(label, milliseconds, algorithmic flops)] recorded since the last read."""
+        buf = ctypes.create_string_buffer(1 << 20)
+        lib.call('stx_profile_read', self.handle, buf, len(buf), None)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            label, ms, flops = line.split('\t')
+            rows.append((label, float(ms), float(flops)))
+        return rows
+
     def last_tile_ms(self):
         ms = ctypes.c_float(0)
         lib.call('stx_last_tile_ms', self.handle, ctypes.byref(ms))

@@ -38,10 +38,12 @@ def tile_grid(img_hw, tile_size):
 class TileFarm:
     """One host process, one engine per entry of ``devices`` (the reference's ``--devices``)."""
 
-    def __init__(self, net, devices=(0,), weights=None, verbose=True):
+    def __init__(self, net, devices=(0,), weights=None, verbose=True, engines=None):
         self.net = net
         self.verbose = verbose
-        self.engines = [TileEngine(net, d, weights) for d in devices]
+        self.owns_engines = engines is None
+        self.engines = engines if engines is not None else \
+            [TileEngine(net, d, weights) for d in devices]
         self.master = self.engines[0]
         self._tiles = {}        # (engine index, slot, th, tw) -> (tile DeviceArray, grad DeviceArray)
         self._staging = {}      # (slot, th, tw) -> master-side staging for remote engines
@@ -53,8 +55,9 @@ class TileFarm:
                 b.free()
         self._tiles.clear()
         self._staging.clear()
-        for e in self.engines:
-            e.close()
+        if self.owns_engines:
+            for e in self.engines:
+                e.close()
 
     def layers(self):
         return self.net.blob_names()
