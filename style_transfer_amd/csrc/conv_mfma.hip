@@ -28,6 +28,7 @@
 namespace stx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKernelArgs {
     const float *x;
@@ -40,7 +41,8 @@ struct ConvKernelArgs {
     int n_chunks;          // ceil(K / KC)
     int tiles_x, tiles_y;  // pixel tiles
     int w_row_stride;      // floats between consecutive k rows of the weight source
-    long w_tile_stride;    // floats between consecutive output-channel tiles (packed mode)
+    int w_tile_stride;     // floats between consecutive output-channel tiles (packed mode)
+    int x_bytes, w_bytes;  // sizes of the x and w buffers (hardware bounds check of the loads)
     int relu;
 };
 
@@ -84,58 +86,60 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     const int m0 = mtile * BM;
     const int HW = a.H * a.W;
 
-    const float *wsrc = PACKED ? a.w + (long)mtile * a.w_tile_stride : a.w + m0;
+    // ---- global -> register staging through buffer loads.  Out-of-range elements (zero padding
+    // at the tile border, channel / row padding) get an offset beyond the descriptor's range and
+    // come back as 0 from the hardware bounds check, so no select touches the loaded data and
+    // the loads stay in flight across the whole MFMA loop of the current chunk.  All per-lane
+    // offsets are computed once; a chunk only changes the scalar offset.
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+    unsigned xvoff[NX], wvoff[NW];
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+        const int e = tid + n * NT;
+        const int ci = e / (XR * XC);
+        const int rem = e - ci * (XR * XC);
+        const int r = rem / XC, c = rem - r * XC;
+        const int yy = y0 - PAD + r, xx = x0 - PAD + c;
+        const bool ok = (NX * NT == X_FLOATS || e < X_FLOATS) && (unsigned)yy < (unsigned)a.H &&
+                        (unsigned)xx < (unsigned)a.W;
+        xvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+    }
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int f = tid + n * NT;
+        const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+        bool ok = NW * NT == W_VEC4 || f < W_VEC4;
+        if (!PACKED) ok = ok && m0 + c4 < a.M;   // rows beyond K fall off the end of the matrix
+        wvoff[n] = ok ? (unsigned)(row * a.w_row_stride + c4) * 4u : kOob;
+    }
+    const unsigned w_base = PACKED ? (unsigned)(mtile * a.w_tile_stride) * 4u : (unsigned)m0 * 4u;
+    const unsigned w_chunk = (unsigned)(KC * KK * a.w_row_stride) * 4u;
+    const unsigned x_chunk = (unsigned)(KC * HW) * 4u;
 
-    float4 wreg[NW];
-    float xreg[NX];
-
+    u32x4 wreg[NW];
+    unsigned xreg[NX];
     auto load_stage = [&](int chunk) {
-        const int krow0 = chunk * KC * KK;
+        const unsigned ws = w_base + (unsigned)chunk * w_chunk;
+        const unsigned xs = (unsigned)chunk * x_chunk;
 #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int f = tid + n * NT;
-            const int row = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            if (PACKED) {
-                // packed slabs are padded to whole stages: always in bounds
-                const bool ok = NW * NT == W_VEC4 || f < W_VEC4;
-                wreg[n] = *reinterpret_cast<const float4 *>(
-                    wsrc + (ok ? (long)(krow0 + row) * BM + c4 : 0));
-            } else {
-                // dense symmetric matrix: M is a multiple of 4, rows are 16-byte aligned
-                const bool ok = (NW * NT == W_VEC4 || f < W_VEC4) && krow0 + row < a.K &&
-                                m0 + c4 < a.M;
-                const float4 v = *reinterpret_cast<const float4 *>(
-                    ok ? wsrc + (long)(krow0 + row) * a.w_row_stride + c4 : a.w);
-                wreg[n] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        const int c0 = chunk * KC;
-        // Branch-free: out-of-range elements (zero padding at the tile border, channel padding)
-        // read element 0 and are zeroed by a select, so all NX loads are issued back to back.
+        for (int n = 0; n < NW; ++n) wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[n], ws, 0);
 #pragma unroll
-        for (int n = 0; n < NX; ++n) {
-            const int e = tid + n * NT;
-            const int ci = e / (XR * XC);
-            const int rem = e - ci * (XR * XC);
-            const int r = rem / XC, c = rem - r * XC;
-            const int yy = y0 - PAD + r, xx = x0 - PAD + c;
-            const bool ok = (NX * NT == X_FLOATS || e < X_FLOATS) && c0 + ci < a.K &&
-                            (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            const int off = ok ? (c0 + ci) * HW + yy * a.W + xx : 0;
-            const float v = a.x[off];
-            xreg[n] = ok ? v : 0.f;
-        }
+        for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
     };
     auto store_stage = [&]() {
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int f = tid + n * NT;
-            if (NW * NT == W_VEC4 || f < W_VEC4) reinterpret_cast<float4 *>(Wl)[f] = wreg[n];
+            if (NW * NT == W_VEC4 || f < W_VEC4) reinterpret_cast<u32x4 *>(Wl)[f] = wreg[n];
         }
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
             const int e = tid + n * NT;
-            if (NX * NT == X_FLOATS || e < X_FLOATS) Xl[e] = xreg[n];
+            if (NX * NT == X_FLOATS || e < X_FLOATS) reinterpret_cast<unsigned *>(Xl)[e] = xreg[n];
         }
     };
 
@@ -155,6 +159,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
         const int pb = wn * TN + j;
         xoff[j] = half * (XR * XC) + (pb / SEGS) * XC + (pb % SEGS) * 32 + l31;
     }
+    // operands of k-step s (a pair of input channels q, tap t)
+    constexpr int NS = (KC / 2) * KK;
+    static_assert(NS % 2 == 0, "k-steps are software-pipelined in pairs");
+    auto load_a = [&](int s, float (&av)[TM]) {
+        const int q = s / KK, t = s % KK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = wl[((2 * q) * KK + t) * BM + i * 32];
+    };
+    auto load_b = [&](int s, float (&bv)[TN]) {
+        const int q = s / KK, t = s % KK;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bv[j] = Xl[(2 * q) * (XR * XC) + (t / KS) * XC + (t % KS) + xoff[j]];
+    };
+    auto multiply = [&](const float (&av)[TM], const float (&bv)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
 
     load_stage(0);
     store_stage();
@@ -163,24 +188,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         const bool more = chunk + 1 < a.n_chunks;
         if (more) load_stage(chunk + 1);
+        // two operand register sets: the LDS reads of step s+1 are issued before the MFMAs of
+        // step s, so their latency hides behind 8 x 64 cycles of matrix work
+        float a0[TM], b0[TN], a1[TM], b1[TN];
+        load_a(0, a0);
+        load_b(0, b0);
 #pragma unroll
-        for (int q = 0; q < KC / 2; ++q) {
-#pragma unroll
-            for (int t = 0; t < KK; ++t) {
-                const int ky = t / KS, kx = t % KS;
-                float av[TM], bv[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = wl[((2 * q) * KK + t) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bv[j] = Xl[(2 * q) * (XR * XC) + ky * XC + kx + xoff[j]];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j],
-                                                                         0, 0, 0);
+        for (int s = 0; s < NS; s += 2) {
+            // sched_barrier pins "reads of step s+1, then MFMAs of step s": without it the
+            // scheduler sinks each read to just before its first use and stalls on LDS latency
+            load_a(s + 1, a1);
+            load_b(s + 1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < NS) {
+                load_a(s + 2, a0);
+                load_b(s + 2, b0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (more) {
@@ -379,7 +407,17 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     a.tiles_x = ceil_div(p.W, cfg.pc);
     a.tiles_y = ceil_div(p.H, cfg.pr);
     a.w_row_stride = packed ? cfg.bm : p.M;
-    a.w_tile_stride = packed ? (long)a.n_chunks * cfg.kc * p.ksize * p.ksize * cfg.bm : 0;
+    a.w_tile_stride = packed ? a.n_chunks * cfg.kc * p.ksize * p.ksize * cfg.bm : 0;
+    const double xb = 4.0 * p.K * (double)p.H * p.W;
+    const double wb = packed ? 4.0 * (double)conv_packed_floats(cfg, p.K, p.M, p.ksize)
+                             : 4.0 * (double)p.K * p.M;
+    if (xb >= 2147483648.0 || wb >= 2147483648.0) {
+        set_error("conv_launch: a %d x %d x %d plane set exceeds the 2 GiB buffer-addressing limit "
+                  "of the kernel (use a smaller --tile-size)", p.K, p.H, p.W);
+        return STX_ERR_UNSUPPORTED;
+    }
+    a.x_bytes = (int)xb;
+    a.w_bytes = (int)wb;
     a.relu = p.relu;
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
 
