@@ -270,7 +270,7 @@ struct ConvVariant {
 
 static const ConvVariant kVariants[] = {
     /*0*/ {3, 8, 2, 4, 2, 2, 8, 32},   // BM 128 x 256 px : wide middle layers
-    /*1*/ {3, 4, 2, 4, 1, 4, 8, 64},   // BM  64 x 512 px : 64-channel layers at full resolution
+    /*1*/ {3, 8, 2, 4, 1, 4, 8, 64},   // BM  64 x 512 px : 64-channel layers at full resolution
     /*2*/ {3, 8, 2, 2, 1, 4, 8, 32},   // BM  64 x 256 px : deep layers with few pixels
     /*3*/ {3, 8, 1, 2, 1, 4, 8, 32},   // BM  32 x 256 px : backward into the 3-channel image
     /*4*/ {3, 4, 2, 4, 1, 4, 8, 64},   // BM  64 x 512 px, KC 4 : first layer (3 input channels)
@@ -377,7 +377,7 @@ int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int k
     }
 
 STX_CONV_VARIANT(0, 3, 8, 2, 4, 2, 2, 8, 32)
-STX_CONV_VARIANT(1, 3, 4, 2, 4, 1, 4, 8, 64)
+STX_CONV_VARIANT(1, 3, 8, 2, 4, 1, 4, 8, 64)
 STX_CONV_VARIANT(2, 3, 8, 2, 2, 1, 4, 8, 32)
 STX_CONV_VARIANT(3, 3, 8, 1, 2, 1, 4, 8, 32)
 STX_CONV_VARIANT(4, 3, 4, 2, 4, 1, 4, 8, 64)

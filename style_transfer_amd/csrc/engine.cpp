@@ -853,7 +853,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                     return STX_ERR_UNSUPPORTED;
                 }
                 const GramPlan plan = gram_plan(C, HW);
-                const size_t fin_blocks = ceil_div(C * C, 256);
+                const size_t fin_blocks = ceil_div(C * C, 64);
                 STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
                 STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
                 STX_TRY(e->sgrad.ensure(b.count() * sizeof(float)));

@@ -34,8 +34,8 @@ GramPlan gram_plan(int C, int HW) {
     p.HW = HW;
     const int T = ceil_div(C, kGT);
     p.tiles = T * (T + 1) / 2;
-    int splits = std::max(1, 1024 / p.tiles);
-    splits = std::min(splits, ceil_div(HW, 4 * kGP));   // at least four stages per slice
+    int splits = std::max(1, 512 / p.tiles);
+    splits = std::min(splits, ceil_div(HW, 8 * kGP));   // at least eight stages per slice
     splits = std::max(splits, 1);
     p.splits = splits;
     p.partial_floats = (size_t)p.splits * p.tiles * kGT * kGT;
@@ -51,6 +51,7 @@ __device__ __forceinline__ void tile_coords(int tile, int &ti, int &tj) {
     tj = tile - r * (r + 1) / 2;
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__restrict__ F, int C,
                                                               int HW, int tiles, int slice,
                                                               float *__restrict__ partials) {
@@ -71,30 +72,65 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // each thread stages 16 floats of the A tile and 16 of the B tile per stage:
-    // element e = tid + 256*n -> channel e / 64, pixel e % 64 (coalesced along pixels)
+    // each thread stages 16 floats of the A tile and 16 of the B tile per stage.  VEC4 (h*w a
+    // multiple of 4, so every channel row is 16-byte aligned): four float4 per tile, a wave
+    // covers 4 channel rows x 256 B; otherwise scalar loads, one channel row per wave.
     float ra[16], rb[16];
     auto load = [&](int p0) {
+        if (VEC4) {
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            const int e = tid + 256 * n;
-            const int ch = e >> 6, px = p0 + (e & 63);
-            const int ca = ti * kGT + ch, cb = tj * kGT + ch;
-            const bool okp = px < p_end;
-            const bool oka = okp && ca < C, okb = okp && cb < C && !diag;
-            const float va = F[oka ? (size_t)ca * HW + px : 0];
-            const float vb = F[okb ? (size_t)cb * HW + px : 0];
-            ra[n] = oka ? va : 0.f;
-            rb[n] = okb ? vb : 0.f;
+            for (int n = 0; n < 4; ++n) {
+                const int e = tid + 256 * n;                 // float4 index in the 64 x 16 tile
+                const int ch = e >> 4, px = p0 + (e & 15) * 4;
+                const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+                const bool okp = px < p_end;                 // p_end is a multiple of 4 here
+                const bool oka = okp && ca < C, okb = okp && cb < C && !diag;
+                const float4 va = *reinterpret_cast<const float4 *>(F + (oka ? (size_t)ca * HW + px : 0));
+                const float4 vb = *reinterpret_cast<const float4 *>(F + (okb ? (size_t)cb * HW + px : 0));
+                ra[4 * n + 0] = oka ? va.x : 0.f;
+                ra[4 * n + 1] = oka ? va.y : 0.f;
+                ra[4 * n + 2] = oka ? va.z : 0.f;
+                ra[4 * n + 3] = oka ? va.w : 0.f;
+                rb[4 * n + 0] = okb ? vb.x : 0.f;
+                rb[4 * n + 1] = okb ? vb.y : 0.f;
+                rb[4 * n + 2] = okb ? vb.z : 0.f;
+                rb[4 * n + 3] = okb ? vb.w : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int e = tid + 256 * n;
+                const int ch = e >> 6, px = p0 + (e & 63);
+                const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+                const bool okp = px < p_end;
+                const bool oka = okp && ca < C, okb = okp && cb < C && !diag;
+                const float va = F[oka ? (size_t)ca * HW + px : 0];
+                const float vb = F[okb ? (size_t)cb * HW + px : 0];
+                ra[n] = oka ? va : 0.f;
+                rb[n] = okb ? vb : 0.f;
+            }
         }
     };
     auto store = [&]() {
+        if (VEC4) {
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            const int e = tid + 256 * n;
-            const int ch = e >> 6, px = e & 63;
-            At[ch * kGLd + px] = ra[n];
-            if (!diag) Bt[ch * kGLd + px] = rb[n];
+            for (int n = 0; n < 4; ++n) {
+                const int e = tid + 256 * n;
+                const int ch = e >> 4, px = (e & 15) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    At[ch * kGLd + px + k] = ra[4 * n + k];
+                    if (!diag) Bt[ch * kGLd + px + k] = rb[4 * n + k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int e = tid + 256 * n;
+                const int ch = e >> 6, px = e & 63;
+                At[ch * kGLd + px] = ra[n];
+                if (!diag) Bt[ch * kGLd + px] = rb[n];
+            }
         }
     };
 
@@ -129,31 +165,59 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__res
 int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials) {
     int slice = ceil_div(plan.HW, plan.splits);
     slice = ceil_div(slice, kGP) * kGP;
-    gram_partial_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(feat, plan.C, plan.HW, plan.tiles,
-                                                                  slice, partials);
+    const bool vec4 = plan.HW % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
+    if (vec4)
+        gram_partial_kernel<true><<<plan.tiles * plan.splits, 256, 0, s>>>(
+            feat, plan.C, plan.HW, plan.tiles, slice, partials);
+    else
+        gram_partial_kernel<false><<<plan.tiles * plan.splits, 256, 0, s>>>(
+            feat, plan.C, plan.HW, plan.tiles, slice, partials);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
 
-// One thread per (i, j) of the full C x C matrix.
+// 64 consecutive (i, j) elements per workgroup, each summed by four "split lanes" that walk the
+// slices with a stride of four (independent partial sums -> memory-level parallelism); the four
+// lanes are then added in a fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restrict__ partials, int C,
                                                           int tiles, int splits, float scale,
                                                           float *__restrict__ gram,
                                                           const float *__restrict__ target,
                                                           float *__restrict__ dsym,
                                                           float *__restrict__ block_sumsq) {
-    __shared__ float red[4];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    float sq = 0.f;
-    if (idx < C * C) {
-        const int i = idx / C, j = idx % C;
-        const int lo = min(i, j), hi = max(i, j);      // element (hi, lo) of the lower triangle
+    __shared__ float lane_sum[4][64];
+    __shared__ float red[64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + el;
+    const bool valid = idx < C * C;
+    int i = 0, j = 0, lo = 0, hi = 0;
+    float sum = 0.f;
+    if (valid) {
+        i = idx / C;
+        j = idx % C;
+        lo = min(i, j);
+        hi = max(i, j);                                // element (hi, lo) of the lower triangle
         const int ti = hi / kGT, tj = lo / kGT;
         const int tile = ti * (ti + 1) / 2 + tj;
+        const size_t stride = (size_t)tiles * (kGT * kGT);
         const float *p = partials + (size_t)tile * (kGT * kGT) + (hi % kGT) * kGT + (lo % kGT);
-        float sum = 0.f;
-        for (int s = 0; s < splits; ++s) sum += p[(size_t)s * tiles * (kGT * kGT)];
-        const float g = sum * scale;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int s = sl;
+        for (; s + 12 < splits; s += 16) {
+            s0 += p[(size_t)s * stride];
+            s1 += p[(size_t)(s + 4) * stride];
+            s2 += p[(size_t)(s + 8) * stride];
+            s3 += p[(size_t)(s + 12) * stride];
+        }
+        for (; s < splits; s += 4) s0 += p[(size_t)s * stride];
+        sum = (s0 + s1) + (s2 + s3);
+    }
+    lane_sum[sl][el] = sum;
+    __syncthreads();
+    float sq = 0.f;
+    if (sl == 0 && valid) {
+        const float g = ((lane_sum[0][el] + lane_sum[1][el]) + (lane_sum[2][el] + lane_sum[3][el])) *
+                        scale;
         if (gram) gram[idx] = i >= j ? g : 0.f;
         if (target) {
             const float d = g - target[hi * C + lo];
@@ -162,11 +226,13 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
         }
     }
     if (block_sumsq) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        if (sl == 0) red[el] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) block_sumsq[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int k = 0; k < 64; ++k) t += red[k];
+            block_sumsq[blockIdx.x] = t;
+        }
     }
 }
 
@@ -193,7 +259,7 @@ int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out)
 
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
                        const float *target, float *dsym, float *sumsq) {
-    const int blocks = ceil_div(plan.C * plan.C, 256);
+    const int blocks = ceil_div(plan.C * plan.C, 64);
     // block partial sums live behind the Gram partials (the caller sizes the buffer for both)
     float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
     const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
