@@ -80,6 +80,7 @@ struct ConvConfig {
 };
 
 ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W);
+ConvConfig conv_config_by_id(int id);
 int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W);
 // Packed weight buffer size (floats) for a [M][K][ks][ks] filter bank under cfg.
 size_t conv_packed_floats(const ConvConfig &cfg, int K, int M, int ksize);

@@ -22,6 +22,7 @@
 // v_fma_f32), accumulation in fp32 like Caffe's SGEMM.
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -295,6 +296,8 @@ static ConvConfig make_config(int id) {
     return c;
 }
 
+ConvConfig conv_config_by_id(int id) { return make_config(id); }
+
 int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W) {
     return ceil_div(M, cfg.bm) * ceil_div(H, cfg.pr) * ceil_div(W, cfg.pc);
 }
@@ -303,14 +306,16 @@ ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
     if (ksize == 1) return make_config(M >= 128 ? 6 : 7);
     if (K <= 4) return make_config(4);
     if (M <= 32) return make_config(3);
-    // prefer the largest tile that still gives every CU two workgroups (256 CUs)
-    const int order_wide[] = {0, 2, 5};
-    const int order_64[] = {1, 2, 5};
-    const int *order = M <= 64 ? order_64 : order_wide;
-    for (int i = 0; i < 3; ++i) {
-        ConvConfig c = make_config(order[i]);
-        if (conv_num_workgroups(c, M, H, W) >= 512 || i == 2) return c;
+    if (const char *force = getenv("STX_CONV_FORCE")) {   // tuning aid: force one tile config
+        const int id = atoi(force);
+        if (id >= 0 && id <= 5 && id != 3 && id != 4) return make_config(id);
     }
+    // Static default (the engine autotunes per shape on top of this): measured on MI355X, many
+    // small workgroups beat few large ones because co-resident workgroups run out of phase and
+    // cover each other's stage swaps and epilogues -- 64 channels x 128 pixels (5 workgroups per
+    // CU) unless the plane is so large that 256-pixel tiles still give >= 8 workgroups per CU.
+    ConvConfig c2 = make_config(2);
+    if (conv_num_workgroups(c2, M, H, W) >= 2048 && K >= 128) return c2;
     return make_config(5);
 }
 

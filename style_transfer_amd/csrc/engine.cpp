@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -111,7 +112,7 @@ using namespace stx;
 struct stx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
     std::vector<Layer> layers;
     std::vector<Blob> blobs;
@@ -130,6 +131,10 @@ struct stx_engine {
     size_t dscalars_cap = 64, dscalars_used = 0;
     DevBuf red_scratch;                // float partials for image-op reductions
     std::vector<PendingLoss> pending;
+
+    // tile-config autotuning: (ksize, K, M, H, W, epilogue) -> config id, measured once per shape
+    std::map<std::vector<int>, int> tuned;
+    bool autotune = true;
 
     // optional per-kernel-group timing (stx_profile_enable): event pairs around launch groups
     bool profiling = false;
@@ -282,17 +287,54 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
     return STX_OK;
 }
 
+// Picks the tile configuration of a packed-weight convolution.  All configurations accumulate k
+// in the same order, so they produce bit-identical results; which one is fastest depends on how
+// many workgroups the plane yields (co-resident workgroups hide each other's stage swaps and
+// epilogues).  The first time a shape is seen every candidate is timed with HIP events on the
+// engine stream (a few launches, once per shape and scale) and the winner is cached.
+int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out) {
+    const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
+    *out = fallback;
+    if (!e->autotune || p.ksize != 3 || p.K <= 4 || p.M <= 32) return STX_OK;
+    const std::vector<int> key = {p.ksize, p.K, p.M, p.H, p.W, p.epilogue};
+    auto it = e->tuned.find(key);
+    if (it != e->tuned.end()) {
+        *out = conv_config_by_id(it->second);
+        return STX_OK;
+    }
+    const int candidates[] = {0, 1, 2, 5};
+    float best_ms = 1e30f;
+    int best = fallback.id;
+    for (int id : candidates) {
+        const ConvConfig cfg = conv_config_by_id(id);
+        if (cfg.bm > 64 && p.M <= 64) continue;            // half-empty channel tiles
+        const float *packed = nullptr;
+        STX_TRY(get_packed(e, li, dir, cfg, &packed));
+        p.w = packed;
+        STX_TRY(conv_launch(e->stream, cfg, p, true));     // warm (also builds nothing lazily)
+        STX_HIP(hipEventRecord(e->ev_tune0, e->stream));
+        for (int r = 0; r < 2; ++r) STX_TRY(conv_launch(e->stream, cfg, p, true));
+        STX_HIP(hipEventRecord(e->ev_tune1, e->stream));
+        STX_HIP(hipEventSynchronize(e->ev_tune1));
+        float ms = 0.f;
+        STX_HIP(hipEventElapsedTime(&ms, e->ev_tune0, e->ev_tune1));
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = id;
+        }
+    }
+    e->tuned[key] = best;
+    *out = conv_config_by_id(best);
+    return STX_OK;
+}
+
 int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     const Layer &L = e->layers[li];
     const Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
     const ConvParams &cp = e->conv[li];
-    const ConvConfig cfg = conv_pick_config(cp.ks, cp.cin, cp.cout, b.h, b.w);
-    const float *packed = nullptr;
-    STX_TRY(get_packed(e, li, 0, cfg, &packed));
     ConvProblem p{};
     p.x = b.data.f();
-    p.w = packed;
     p.y = t.data.f();
     p.bias = cp.b.f();
     p.K = cp.cin;
@@ -302,6 +344,11 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     p.ksize = cp.ks;
     p.relu = (t.relu || force_relu) ? 1 : 0;
     p.epilogue = kEpiForward;
+    ConvConfig cfg;
+    STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
+    const float *packed = nullptr;
+    STX_TRY(get_packed(e, li, 0, cfg, &packed));
+    p.w = packed;
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -311,12 +358,8 @@ int run_conv_backward(stx_engine *e, int li) {
     Blob &b = e->blobs[L.bottom_blob];
     const Blob &t = e->blobs[L.top_blob];
     const ConvParams &cp = e->conv[li];
-    const ConvConfig cfg = conv_pick_config(cp.ks, cp.cout, cp.cin, b.h, b.w);
-    const float *packed = nullptr;
-    STX_TRY(get_packed(e, li, 1, cfg, &packed));
     ConvProblem p{};
     p.x = t.diff.f();
-    p.w = packed;
     p.y = b.diff.f();
     p.mask = b.relu ? b.data.f() : nullptr;
     p.K = cp.cout;
@@ -325,6 +368,11 @@ int run_conv_backward(stx_engine *e, int li) {
     p.W = b.w;
     p.ksize = cp.ks;
     p.epilogue = kEpiDgrad;
+    ConvConfig cfg;
+    STX_TRY(choose_conv_config(e, li, 1, p, &cfg));
+    const float *packed = nullptr;
+    STX_TRY(get_packed(e, li, 1, cfg, &packed));
+    p.w = packed;
     ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -515,6 +563,9 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     STX_HIP(hipEventCreate(&e->ev_start));
     STX_HIP(hipEventCreate(&e->ev_stop));
+    STX_HIP(hipEventCreate(&e->ev_tune0));
+    STX_HIP(hipEventCreate(&e->ev_tune1));
+    if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
     e->scalars_cap = kScalarFloats;
     STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
@@ -554,6 +605,8 @@ void stx_engine_destroy(stx_engine *e) {
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    if (e->ev_tune0) (void)hipEventDestroy(e->ev_tune0);
+    if (e->ev_tune1) (void)hipEventDestroy(e->ev_tune1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
