@@ -51,9 +51,29 @@ inline int pooled_len(int n) { return n >= 2 ? (n - 2 + 1) / 2 + 1 : 1; }  // ce
 
 // Epilogue selection for the implicit-GEMM MFMA kernel.
 enum ConvEpilogue {
-    kEpiForward = 0,   // y = [relu](acc + bias)
-    kEpiDgrad = 1,     // y = acc * (mask > 0)      (mask optional)
-    kEpiSymm = 2       // y = acc, plus per-workgroup sum|y| partials
+    kEpiForward = 0,      // y = [relu](acc + bias)
+    kEpiDgrad = 1,        // y = acc * (mask > 0)      (mask optional)
+    kEpiSymm = 2,         // y = acc, plus per-workgroup sum|y| partials
+    kEpiDgradInject = 3   // kEpiDgrad plus the loss-gradient terms of the produced blob (internal)
+};
+
+struct ContentWindow {
+    int C, fh, fw;          // tile feature size
+    int ch, cw;             // full content map size
+    int oy, ox;             // window origin in the rolled map
+    int sy, sx;             // roll shifts (rows, cols)
+};
+
+// Loss-gradient terms added by the backward-data epilogue to the gradient it produces (the
+// reference's saxpy(lw*w, normalize(x), diff[layer]), style_transfer.py:580,592-593):
+//   y += c_coef / (c_sums[1]/n + EPS) * (feat - content[window])     (content term, first)
+//   y += s_coef / (s_abs_sum[0]/n + EPS) * sgrad                     (style term)
+struct ConvInject {
+    const float *sgrad = nullptr, *s_abs_sum = nullptr;
+    float s_coef = 0.f;
+    const float *content = nullptr, *c_sums = nullptr, *feat = nullptr;
+    float c_coef = 0.f;
+    ContentWindow win{};
 };
 
 struct ConvProblem {
@@ -67,6 +87,7 @@ struct ConvProblem {
     int ksize;             // 3 (pad 1) or 1 (pad 0)
     int relu;              // kEpiForward
     int epilogue;
+    ConvInject inject;     // kEpiDgrad, optional
 };
 
 // Tile configuration chosen for a problem; weights must be packed for the same (bm, kc).
@@ -109,12 +130,18 @@ int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &pla
 
 // sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
 // content map.
-struct ContentWindow {
-    int C, fh, fw;          // tile feature size
-    int ch, cw;             // full content map size
-    int oy, ox;             // window origin in the rolled map
-    int sy, sx;             // roll shifts (rows, cols)
-};
+#ifdef __HIPCC__
+// Rolled content value at tile-feature position (c, y, x):
+// roll2(Fc, (sx, sy))[c][oy + y][ox + x] = Fc[c][(oy + y - sy) mod ch][(ox + x - sx) mod cw]
+__device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, int y, int x) {
+    int yy = (w.oy + y - w.sy) % w.ch;
+    int xx = (w.ox + x - w.sx) % w.cw;
+    if (yy < 0) yy += w.ch;
+    if (xx < 0) xx += w.cw;
+    return ((size_t)c * w.ch + yy) * w.cw + xx;
+}
+#endif
+
 int content_sums_launch(hipStream_t s, const float *feat, const float *content,
                         const ContentWindow &win, float *sums /*[2]*/);
 // diff (=|+=) coef / (abs_sum/n + EPS) * term, term = S (style) or F - Fc (content).

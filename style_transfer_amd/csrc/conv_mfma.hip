@@ -45,6 +45,7 @@ struct ConvKernelArgs {
     int w_tile_stride;     // floats between consecutive output-channel tiles (packed mode)
     int x_bytes, w_bytes;  // sizes of the x and w buffers (hardware bounds check of the loads)
     int relu;
+    ConvInject inj;        // kEpiDgradInject
 };
 
 // KS: kernel size (3 -> pad 1, 1 -> pad 0).  KC: reduction channels per stage (even).
@@ -220,6 +221,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
 
     // ---- epilogue: D register r of a block holds row (r&3) + 8*(r>>2) + 4*half, column l31.
     float abs_sum = 0.f;
+    float s_scale = 0.f, c_scale = 0.f;
+    if (EPI == kEpiDgradInject) {
+        // normalize(): x * 1 / (sum|x| / size + EPS) (num_utils.py:85-87), times lw * weight
+        const float n = (float)((size_t)a.M * HW);
+        if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
+        if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pb = wn * TN + j;
@@ -239,6 +247,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
                         if (a.relu) v = fmaxf(v, 0.f);
                     } else if (EPI == kEpiDgrad) {
                         if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                    } else if (EPI == kEpiDgradInject) {
+                        if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                        if (a.inj.content)
+                            v += c_scale * (a.inj.feat[idx] -
+                                            a.inj.content[content_index(a.inj.win, m, yy, xx)]);
+                        if (a.inj.sgrad) v += s_scale * a.inj.sgrad[idx];
                     } else {
                         abs_sum += fabsf(v);
                     }
@@ -424,32 +438,44 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     a.x_bytes = (int)xb;
     a.w_bytes = (int)wb;
     a.relu = p.relu;
+    a.inj = p.inject;
+    const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
 
 #define STX_DISPATCH(ID)                                                                          \
     case ID:                                                                                      \
         if (p.epilogue == kEpiForward && packed)                                                  \
             return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
+        if (inject && packed) return launch_##ID<kEpiDgradInject, true>(s, cfg, a, n_wg);          \
         if (p.epilogue == kEpiDgrad && packed) return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg); \
+        break;
+#define STX_DISPATCH_NOINJ(ID)                                                                    \
+    case ID:                                                                                      \
+        if (p.epilogue == kEpiForward && packed)                                                  \
+            return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
+        if (p.epilogue == kEpiDgrad && packed && !inject)                                         \
+            return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg);                                 \
         break;
 #define STX_DISPATCH_SYMM(ID)                                                                     \
     case ID:                                                                                      \
         if (p.epilogue == kEpiSymm && !packed) return launch_##ID<kEpiSymm, false>(s, cfg, a, n_wg); \
         if (p.epilogue == kEpiForward && packed)                                                  \
             return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
-        if (p.epilogue == kEpiDgrad && packed) return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg); \
+        if (p.epilogue == kEpiDgrad && packed && !inject)                                         \
+            return launch_##ID<kEpiDgrad, true>(s, cfg, a, n_wg);                                 \
         break;
     switch (cfg.id) {
         STX_DISPATCH(0)
         STX_DISPATCH(1)
         STX_DISPATCH(2)
-        STX_DISPATCH(3)
-        STX_DISPATCH(4)
+        STX_DISPATCH_NOINJ(3)
+        STX_DISPATCH_NOINJ(4)
         STX_DISPATCH(5)
         STX_DISPATCH_SYMM(6)
         STX_DISPATCH_SYMM(7)
     }
 #undef STX_DISPATCH
+#undef STX_DISPATCH_NOINJ
 #undef STX_DISPATCH_SYMM
     set_error("conv_launch: no kernel for config %d epilogue %d packed %d", cfg.id, p.epilogue,
               (int)packed);

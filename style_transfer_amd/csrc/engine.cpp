@@ -112,6 +112,10 @@ using namespace stx;
 struct stx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // loss terms of the tapped blobs (overlaps the backward pass)
+    hipEvent_t ev_fwd = nullptr;
+    std::vector<hipEvent_t> ev_tap;
+    std::vector<std::unique_ptr<DevBuf>> sgrad_tap;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
     std::vector<Layer> layers;
@@ -122,7 +126,7 @@ struct stx_engine {
     std::vector<StyleTarget> styles;
     int n_contents = 0, n_styles = 0;
 
-    DevBuf sgrad, gram_partials, gram, dsym, symm_partials, upload, img_scratch;
+    DevBuf gram_partials, gram, dsym, symm_partials, upload, img_scratch;
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
     size_t scalars_cap = 0, scalars_used = 0;
@@ -165,7 +169,9 @@ constexpr size_t kScalarFloats = 1 << 16;   // per-call scalar arena (sums + sma
 struct ProfScope {
     stx_engine *e;
     int index = -1;
-    ProfScope(stx_engine *eng, const std::string &label, double flops) : e(eng) {
+    hipStream_t stream;
+    ProfScope(stx_engine *eng, const std::string &label, double flops, hipStream_t on = nullptr)
+        : e(eng), stream(on ? on : eng->stream) {
         if (!e->profiling) return;
         auto take = [&]() {
             hipEvent_t ev = nullptr;
@@ -179,12 +185,12 @@ struct ProfScope {
         };
         stx_engine::ProfEntry pe{label, flops, take(), take()};
         if (!pe.start || !pe.stop) return;
-        (void)hipEventRecord(pe.start, e->stream);
+        (void)hipEventRecord(pe.start, stream);
         e->prof.push_back(pe);
         index = (int)e->prof.size() - 1;
     }
     ~ProfScope() {
-        if (index >= 0) (void)hipEventRecord(e->prof[index].stop, e->stream);
+        if (index >= 0) (void)hipEventRecord(e->prof[index].stop, stream);
     }
 };
 
@@ -353,7 +359,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     return conv_launch(e->stream, cfg, p, true);
 }
 
-int run_conv_backward(stx_engine *e, int li) {
+int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused) {
     const Layer &L = e->layers[li];
     Blob &b = e->blobs[L.bottom_blob];
     const Blob &t = e->blobs[L.top_blob];
@@ -369,7 +375,10 @@ int run_conv_backward(stx_engine *e, int li) {
     p.ksize = cp.ks;
     p.epilogue = kEpiDgrad;
     ConvConfig cfg;
-    STX_TRY(choose_conv_config(e, li, 1, p, &cfg));
+    STX_TRY(choose_conv_config(e, li, 1, p, &cfg));   // tuned without the injection terms
+    const bool can_fuse = cfg.id != 3 && cfg.id != 4;  // those two have no injecting epilogue
+    if (fused) *fused = inj && can_fuse;
+    if (inj && can_fuse) p.inject = *inj;
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 1, cfg, &packed));
     p.w = packed;
@@ -561,6 +570,15 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
         for (size_t bi = 0; bi < e->blobs.size(); ++bi) e->blobs[bi].scale = 224 / h224[bi];
     }
     STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // The loss terms can run on a second stream beside the backward convolutions
+    // (STX_SIDE_STREAM=1).  Measured on MI355X this is 1.7 % SLOWER (13.24 vs 13.02 ms per 1024^2
+    // tile): the conv kernels already keep every CU's matrix pipe ~90 % busy, so co-resident
+    // Gram / SYMM workgroups only displace conv workgroups.  Default: in order on one stream.
+    if (getenv("STX_SIDE_STREAM") && atoi(getenv("STX_SIDE_STREAM")) == 1)
+        STX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    else
+        e->side = e->stream;
+    STX_HIP(hipEventCreateWithFlags(&e->ev_fwd, hipEventDisableTiming));
     STX_HIP(hipEventCreate(&e->ev_start));
     STX_HIP(hipEventCreate(&e->ev_stop));
     STX_HIP(hipEventCreate(&e->ev_tune0));
@@ -582,6 +600,11 @@ void stx_engine_destroy(stx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->side && e->side != e->stream) (void)hipStreamSynchronize(e->side);
+    for (auto &b : e->sgrad_tap) b->release();
+    for (hipEvent_t ev : e->ev_tap) (void)hipEventDestroy(ev);
+    if (e->ev_fwd) (void)hipEventDestroy(e->ev_fwd);
+    if (e->side && e->side != e->stream) (void)hipStreamDestroy(e->side);
     for (Blob &b : e->blobs) {
         b.data.release();
         b.diff.release();
@@ -593,7 +616,7 @@ void stx_engine_destroy(stx_engine *e) {
     }
     for (auto &c : e->contents) c.feat->release();
     for (auto &s : e->styles) s.gram->release();
-    DevBuf *bufs[] = {&e->sgrad, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
+    DevBuf *bufs[] = {&e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
                       &e->upload, &e->img_scratch, &e->scalars, &e->dscalars, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
     if (e->scalars_host) (void)hipHostFree(e->scalars_host);
@@ -850,8 +873,27 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     PendingLoss pl;
     pl.out = loss_out;
 
-    // ---- injection of the loss gradients of one tapped blob into its diff
-    auto inject = [&](const Tap &tp, bool &diff_written) -> int {
+    // ---- loss terms of the tapped blobs.  They depend only on the forward activations, so they
+    // are all queued right after the forward pass (optionally on a side stream, see
+    // stx_engine_create); the backward walk waits for a tap's event where it reaches that blob.
+    struct Term {
+        bool style;
+        const float *src;        // style: S = sym(tril(G - Gs)) F;  content: the content map
+        const float *sums;       // style: &sum|S|;  content: {sum c^2, sum |c|}
+        float coef;
+        ContentWindow win;
+    };
+    std::vector<std::vector<Term>> terms(order.size());
+    STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
+    STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
+    while (e->ev_tap.size() < order.size()) {
+        hipEvent_t ev;
+        STX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->ev_tap.push_back(ev);
+    }
+    while (e->sgrad_tap.size() < order.size()) e->sgrad_tap.emplace_back(new DevBuf);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const Tap &tp = order[k];
         Blob &b = e->blobs[tp.blob];
         const double lw = tp.t->layer_weight;
         if (tp.t->is_content) {
@@ -879,15 +921,12 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
                 float *sums = e->scalars.f() + si;
                 {
-                    ProfScope scope(e, "content " + b.name, 0.0);
-                    STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
+                    ProfScope scope(e, "content " + b.name, 0.0, e->side);
+                    STX_TRY(content_sums_launch(e->side, b.data.f(), ct.feat->f(), win, sums));
                 }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->content_weight * 0.5});
-                ProfScope scope(e, "inject " + b.name, 0.0);
-                STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), ct.feat->f(), win,
-                                              sums, (float)(lw * tp.t->content_weight),
-                                              diff_written));
-                diff_written = true;
+                terms[k].push_back(Term{false, ct.feat->f(), sums,
+                                        (float)(lw * tp.t->content_weight), win});
             }
             if (!any) {
                 set_error("no content target for layer %s", b.name.c_str());
@@ -895,10 +934,16 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             }
         }
         if (tp.t->is_style) {
-            bool any = false;
+            int n_here = 0;
+            for (const StyleTarget &st : e->styles) n_here += st.blob == tp.blob;
+            if (!n_here) {
+                set_error("no style target for layer %s", b.name.c_str());
+                return STX_ERR_STATE;
+            }
+            STX_TRY(e->sgrad_tap[k]->ensure((size_t)n_here * b.count() * sizeof(float)));
+            int slot = 0;
             for (const StyleTarget &st : e->styles) {
                 if (st.blob != tp.blob) continue;
-                any = true;
                 const int C = b.channels, HW = b.h * b.w;
                 if (C % 4 != 0) {
                     set_error("style layer %s: channel count %d is not a multiple of 4", b.name.c_str(),
@@ -909,14 +954,14 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 const size_t fin_blocks = ceil_div(C * C, 64);
                 STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
                 STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
-                STX_TRY(e->sgrad.ensure(b.count() * sizeof(float)));
+                float *sgrad = e->sgrad_tap[k]->f() + (size_t)slot++ * b.count();
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
                 float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
                 {
-                    ProfScope scope(e, "gram " + b.name, 2.0 * C * C * (double)HW);
-                    STX_TRY(gram_partials_launch(e->stream, b.data.f(), plan, e->gram_partials.f()));
-                    STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr,
+                    ProfScope scope(e, "gram " + b.name, 2.0 * C * C * (double)HW, e->side);
+                    STX_TRY(gram_partials_launch(e->side, b.data.f(), plan, e->gram_partials.f()));
+                    STX_TRY(gram_finish_launch(e->side, e->gram_partials.f(), plan, nullptr,
                                                st.gram->f(), e->dsym.f(), sc));
                 }
                 // S = sym(tril(G - Gs)) . F  with sum|S| partials
@@ -926,7 +971,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 ConvProblem p{};
                 p.x = b.data.f();
                 p.w = e->dsym.f();
-                p.y = e->sgrad.f();
+                p.y = sgrad;
                 p.partials = e->symm_partials.f();
                 p.K = C;
                 p.M = C;
@@ -935,31 +980,47 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 p.ksize = 1;
                 p.epilogue = kEpiSymm;
                 {
-                    ProfScope scope(e, "symm " + b.name, 2.0 * C * C * (double)HW);
-                    STX_TRY(conv_launch(e->stream, cfg, p, false));
-                    STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+                    ProfScope scope(e, "symm " + b.name, 2.0 * C * C * (double)HW, e->side);
+                    STX_TRY(conv_launch(e->side, cfg, p, false));
+                    STX_TRY(sum_partials_launch(e->side, e->symm_partials.f(), n_wg, sc + 1));
                 }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->n_styles});
-                ProfScope scope(e, "inject " + b.name, 0.0);
-                STX_TRY(inject_style_launch(e->stream, b.diff.f(), e->sgrad.f(), b.count(), sc + 1,
-                                            nullptr, 0,
-                                            (float)(lw * tp.t->style_weight / e->n_styles),
-                                            diff_written));
-                diff_written = true;
-            }
-            if (!any) {
-                set_error("no style target for layer %s", b.name.c_str());
-                return STX_ERR_STATE;
+                terms[k].push_back(Term{true, sgrad, sc + 1,
+                                        (float)(lw * tp.t->style_weight / e->n_styles), ContentWindow{}});
             }
         }
+        STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
+    }
+
+    // Adds the terms of tap k to its blob's diff with stand-alone kernels (used for the deepest
+    // tap, for blobs produced by a pooling backward, and when a tap has more than one content or
+    // style term; otherwise the terms ride in the epilogue of the convolution backward above).
+    auto inject = [&](size_t k, bool &diff_written) -> int {
+        Blob &b = e->blobs[order[k].blob];
+        ProfScope scope(e, "inject " + b.name, 0.0);
+        for (const Term &t : terms[k]) {       // content terms come first, like the reference
+            if (t.style)
+                STX_TRY(inject_style_launch(e->stream, b.diff.f(), t.src, b.count(), t.sums, nullptr,
+                                            0, t.coef, diff_written));
+            else
+                STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), t.src, t.win,
+                                              t.sums, t.coef, diff_written));
+            diff_written = true;
+        }
         return STX_OK;
+    };
+    auto fusable = [&](size_t k) {
+        int ns = 0, nc = 0;
+        for (const Term &t : terms[k]) (t.style ? ns : nc)++;
+        return ns <= 1 && nc <= 1;
     };
 
     // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
     int cur = order[0].blob;
     {
+        STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[0], 0));
         bool written = false;
-        STX_TRY(inject(order[0], written));
+        STX_TRY(inject(0, written));
         if (!written)
             STX_HIP(hipMemsetAsync(e->blobs[cur].diff.ptr, 0, e->blobs[cur].count() * sizeof(float),
                                    e->stream));
@@ -969,17 +1030,37 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         const Layer &L = e->layers[li];
         Blob &bot = e->blobs[L.bottom_blob];
         const Blob &top = e->blobs[cur];
+        const int k = tap_of[L.bottom_blob];
+        if (k >= 0) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[k], 0));
+        bool fused = false;
         if (L.type == STX_LAYER_CONV) {
-            STX_TRY(run_conv_backward(e, li));
+            ConvInject inj{};
+            if (k >= 0 && fusable((size_t)k)) {
+                for (const Term &t : terms[k]) {
+                    if (t.style) {
+                        inj.sgrad = t.src;
+                        inj.s_abs_sum = t.sums;
+                        inj.s_coef = t.coef;
+                    } else {
+                        inj.content = t.src;
+                        inj.c_sums = t.sums;
+                        inj.c_coef = t.coef;
+                        inj.win = t.win;
+                        inj.feat = bot.data.f();
+                    }
+                }
+                fused = true;
+            }
+            STX_TRY(run_conv_backward(e, li, fused ? &inj : nullptr, &fused));
         } else {
             ProfScope scope(e, "bwd " + L.name, 0.0);
             STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels, bot.h,
                                          bot.w, L.pool_mode, bot.relu, bot.diff.f()));
         }
         cur = L.bottom_blob;
-        if (tap_of[cur] >= 0) {
+        if (k >= 0 && !fused) {
             bool written = true;   // the upstream gradient is already in diff
-            STX_TRY(inject(order[tap_of[cur]], written));
+            STX_TRY(inject((size_t)k, written));
         }
     }
     STX_TRY(end_timing(e));
@@ -1207,6 +1288,7 @@ int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed) {
     if (!e || (!buf && buf_len)) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     STX_HIP(hipStreamSynchronize(e->stream));
+    STX_HIP(hipStreamSynchronize(e->side));
     std::string out;
     for (auto &pe : e->prof) {
         float ms = 0.f;

@@ -22,16 +22,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Rolled content value at tile-feature position (c, y, x):
-// roll2(Fc, (sx, sy))[c][oy + y][ox + x] = Fc[c][(oy + y - sy) mod ch][(ox + x - sx) mod cw]
-__device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, int y, int x) {
-    int yy = (w.oy + y - w.sy) % w.ch;
-    int xx = (w.ox + x - w.sx) % w.cw;
-    if (yy < 0) yy += w.ch;
-    if (xx < 0) xx += w.cw;
-    return ((size_t)c * w.ch + yy) * w.cw + xx;
-}
-
 constexpr int kRedBlocks = 1024;
 
 __global__ __launch_bounds__(256) void content_sums_kernel(const float *__restrict__ feat,
