@@ -111,6 +111,13 @@ int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int k
                       int transpose_flip, const ConvConfig &cfg, float *packed);
 int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
 
+// 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
+size_t conv_small_packed_floats(int K);
+int conv_small_pack(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                    float *packed);
+int conv_small_launch(hipStream_t s, const float *x, const float *packed, float *y,
+                      const float *mask, int K, int M, int H, int W);
+
 int pool_forward_launch(hipStream_t s, const float *x, int C, int H, int W, int mode, float *y);
 // dx = route(dy) [* (x > 0) when masked]; x is the pool input data (post-ReLU).
 int pool_backward_launch(hipStream_t s, const float *dy, const float *x, int C, int H, int W,

@@ -292,6 +292,7 @@ static const ConvVariant kVariants[] = {
     /*5*/ {3, 8, 2, 1, 1, 4, 4, 32},   // BM  64 x 128 px : smallest planes
     /*6*/ {1, 16, 2, 4, 2, 2, 8, 32},  // 1x1, BM 128 : style-gradient product, C >= 128
     /*7*/ {1, 16, 2, 4, 1, 4, 8, 64},  // 1x1, BM  64 : style-gradient product, C == 64
+    /*8*/ {3, 4, 2, 1, 1, 4, 4, 32},   // BM  64 x 128 px, KC 4 : first layer, small tiles
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -318,7 +319,10 @@ int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W) {
 
 ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
     if (ksize == 1) return make_config(M >= 128 ? 6 : 7);
-    if (K <= 4) return make_config(4);
+    if (K <= 4) {
+        const char *first = getenv("STX_CONV_FIRST");
+        return make_config(first ? atoi(first) : 8);
+    }
     if (M <= 32) return make_config(3);
     if (const char *force = getenv("STX_CONV_FORCE")) {   // tuning aid: force one tile config
         const int id = atoi(force);
@@ -403,6 +407,7 @@ STX_CONV_VARIANT(4, 3, 4, 2, 4, 1, 4, 8, 64)
 STX_CONV_VARIANT(5, 3, 8, 2, 1, 1, 4, 4, 32)
 STX_CONV_VARIANT(6, 1, 16, 2, 4, 2, 2, 8, 32)
 STX_CONV_VARIANT(7, 1, 16, 2, 4, 1, 4, 8, 64)
+STX_CONV_VARIANT(8, 3, 4, 2, 1, 1, 4, 4, 32)
 
 int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     const ConvVariant &v = kVariants[cfg.id];
@@ -470,6 +475,7 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
         STX_DISPATCH(2)
         STX_DISPATCH_NOINJ(3)
         STX_DISPATCH_NOINJ(4)
+        STX_DISPATCH_NOINJ(8)
         STX_DISPATCH(5)
         STX_DISPATCH_SYMM(6)
         STX_DISPATCH_SYMM(7)
@@ -480,6 +486,181 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     set_error("conv_launch: no kernel for config %d epilogue %d packed %d", cfg.id, p.epilogue,
               (int)packed);
     return STX_ERR_UNSUPPORTED;
+}
+
+}  // namespace stx
+
+// ================================================================================================
+// 3x3 convolution with at most 4 output channels: the backward pass into the 3-channel image
+// (dX = W^T (*) dY of conv1_1, style_transfer.py:608).  A 32x32 MFMA tile would waste 29 of its
+// 32 rows; v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4x4 outer products per
+// instruction, which maps to 4 channels x 64 consecutive pixels with K = 1: lane l feeds pixel l
+// as the B operand and weight row (l & 3) as the A operand, and D register r of lane l is output
+// channel r at pixel l.  Three of four rows are useful and the instruction issues at the full
+// 64 FLOP/clk/SIMD rate, so the layer becomes bound by reading the 64-channel gradient once
+// from HBM instead of by matrix work.
+// ================================================================================================
+namespace stx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SmallConvArgs {
+    const float *x;      // [K][H][W]
+    const float *w;      // packed [Kpad * 9][4]
+    float *y;            // [M][H][W], M <= 4
+    const float *mask;   // optional [M][H][W]
+    int K, M, H, W, n_chunks, tiles_x, x_bytes, w_bytes;
+};
+
+template <int KC, int PR>
+__global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
+    constexpr int PC = 64, XR = PR + 2, XC = PC + 2, NT = 256, RW = PR / 4;
+    constexpr int X_FLOATS = KC * XR * XC, W_FLOATS = KC * 9 * 4;
+    constexpr int NX = (X_FLOATS + NT - 1) / NT;
+    static_assert(W_FLOATS / 4 <= NT, "one float4 of weights per thread");
+    __shared__ __attribute__((aligned(16))) float Xl[X_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Wl[W_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int y0 = (blockIdx.x / a.tiles_x) * PR, x0 = (blockIdx.x % a.tiles_x) * PC;
+    const int HW = a.H * a.W;
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+    unsigned xvoff[NX];
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+        const int e = tid + n * NT;
+        const int ci = e / (XR * XC), rem = e - ci * (XR * XC);
+        const int r = rem / XC, c = rem - r * XC;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = e < X_FLOATS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        xvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+    }
+    const unsigned wvoff = tid < W_FLOATS / 4 ? (unsigned)tid * 16u : kOob;
+    unsigned xreg[NX];
+    u32x4 wreg;
+    auto load_stage = [&](int chunk) {
+        wreg = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (unsigned)chunk * (W_FLOATS * 4u), 0);
+        const unsigned xs = (unsigned)chunk * (unsigned)(KC * HW) * 4u;
+#pragma unroll
+        for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
+    };
+    auto store_stage = [&]() {
+        if (tid < W_FLOATS / 4) reinterpret_cast<u32x4 *>(Wl)[tid] = wreg;
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + n * NT;
+            if (e < X_FLOATS) reinterpret_cast<unsigned *>(Xl)[e] = xreg[n];
+        }
+    };
+    f32x4 acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wl = Wl + (lane & 3);
+    const float *xl = Xl + (wave * RW) * XC + lane;
+
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+        const bool more = chunk + 1 < a.n_chunks;
+        if (more) load_stage(chunk + 1);
+#pragma unroll
+        for (int ci = 0; ci < KC; ++ci) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float av = wl[(ci * 9 + t) * 4];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const float bv = xl[ci * (XR * XC) + (r + t / 3) * XC + t % 3];
+                    acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[r], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+    const int xx = x0 + lane;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int yy = y0 + wave * RW + r;
+        if (yy < a.H && xx < a.W) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < a.M) {
+                    const size_t idx = (size_t)m * HW + (size_t)yy * a.W + xx;
+                    float v = acc[r][m];
+                    if (a.mask) v = a.mask[idx] > 0.f ? v : 0.f;
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+constexpr int kSmallKC = 8, kSmallPR = 8;
+
+size_t conv_small_packed_floats(int K) { return (size_t)ceil_div(K, kSmallKC) * kSmallKC * 9 * 4; }
+
+// packed[(k*9 + t)][m] for the backward-data direction of a Caffe bank w[Mo][Ko][3][3]:
+// output channel m = filter input channel, k = filter output channel, taps rotated by 180 degrees
+// (transpose_flip = 1), or the forward direction (0).
+__global__ void pack_small_kernel(const float *__restrict__ w, int Mo, int Ko, int transpose_flip,
+                                  int M, int K, int kpad, float *__restrict__ packed) {
+    const int total = kpad * 9 * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int m = i & 3, t = (i >> 2) % 9, k = i / 36;
+        float v = 0.f;
+        if (m < M && k < K)
+            v = transpose_flip ? w[((size_t)k * Ko + m) * 9 + (8 - t)] : w[((size_t)m * Ko + k) * 9 + t];
+        packed[i] = v;
+    }
+}
+
+int conv_small_pack(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                    float *packed) {
+    const int M = transpose_flip ? Ko : Mo, K = transpose_flip ? Mo : Ko;
+    const int kpad = ceil_div(K, kSmallKC) * kSmallKC;
+    pack_small_kernel<<<ceil_div(kpad * 36, 256), 256, 0, s>>>(w_caffe, Mo, Ko, transpose_flip, M, K,
+                                                               kpad, packed);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int conv_small_launch(hipStream_t s, const float *x, const float *packed, float *y,
+                      const float *mask, int K, int M, int H, int W) {
+    if (M > 4) {
+        set_error("conv_small_launch: M = %d > 4", M);
+        return STX_ERR_ARG;
+    }
+    const double xb = 4.0 * K * (double)H * W;
+    if (xb >= 2147483648.0) {
+        set_error("conv_small_launch: plane set exceeds the 2 GiB buffer-addressing limit");
+        return STX_ERR_UNSUPPORTED;
+    }
+    SmallConvArgs a;
+    a.x = x;
+    a.w = packed;
+    a.y = y;
+    a.mask = mask;
+    a.K = K;
+    a.M = M;
+    a.H = H;
+    a.W = W;
+    a.n_chunks = ceil_div(K, kSmallKC);
+    a.tiles_x = ceil_div(W, 64);
+    a.x_bytes = (int)xb;
+    a.w_bytes = (int)(conv_small_packed_floats(K) * 4);
+    const int n_wg = a.tiles_x * ceil_div(H, kSmallPR);
+    conv3x3_m4_kernel<kSmallKC, kSmallPR><<<n_wg, 256, 0, s>>>(a);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
 }
 
 }  // namespace stx

@@ -374,9 +374,23 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     p.W = b.w;
     p.ksize = cp.ks;
     p.epilogue = kEpiDgrad;
+    if (cp.ks == 3 && cp.cin <= 4) {
+        // backward into a <= 4-channel blob (the image): dedicated 4x4x1-MFMA kernel
+        if (fused) *fused = false;
+        ConvParams &cpm = e->conv[li];
+        auto it = cpm.packed.find(1 * 64 + 63);
+        if (it == cpm.packed.end()) {
+            std::unique_ptr<DevBuf> buf(new DevBuf);
+            STX_TRY(buf->ensure(conv_small_packed_floats(cp.cout) * sizeof(float)));
+            STX_TRY(conv_small_pack(e->stream, cp.w.f(), cp.cout, cp.cin, 1, buf->f()));
+            it = cpm.packed.emplace(1 * 64 + 63, std::move(buf)).first;
+        }
+        ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
+        return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
+    }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 1, p, &cfg));   // tuned without the injection terms
-    const bool can_fuse = cfg.id != 3 && cfg.id != 4;  // those two have no injecting epilogue
+    const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
     const float *packed = nullptr;
@@ -1240,6 +1254,11 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
                               int Cin, int ksize, const float *relu_mask_data, float *dx) {
     if (!e || !dy || !w || !dx) return STX_ERR_ARG;
     STX_TRY(e->set_device());
+    if (ksize == 3 && Cin <= 4) {
+        STX_TRY(e->upload.ensure(conv_small_packed_floats(Cout) * sizeof(float)));
+        STX_TRY(conv_small_pack(e->stream, w, Cout, Cin, 1, e->upload.f()));
+        return conv_small_launch(e->stream, dy, e->upload.f(), dx, relu_mask_data, Cout, Cin, H, W);
+    }
     const ConvConfig cfg = conv_pick_config(ksize, Cout, Cin, H, W);
     const float *packed = nullptr;
     STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 1, cfg, &packed));
