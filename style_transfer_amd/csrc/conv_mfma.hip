@@ -53,7 +53,11 @@ struct ConvKernelArgs {
 // Pixel patch PR rows x PC cols (PC multiple of 32); PR * PC / 32 == TN * WN.
 // PACKED: weights come as pre-tiled [m_tile][k_row][BM] slabs (always in bounds);
 // otherwise as rows of a dense [K][M] matrix (the symmetric style matrix) with bounds masks.
-template <int KS, int KC, int TM, int TN, int WM, int WN, int PR, int PC, int EPI, bool PACKED>
+// DB: two LDS stages.  The next chunk is written into the idle stage in the middle of the current
+// chunk's MFMAs (its global loads were issued a chunk earlier), so a chunk costs one barrier
+// instead of two and no wave ever sits in a write phase with the matrix pipe idle.
+template <int KS, int KC, int TM, int TN, int WM, int WN, int PR, int PC, int EPI, bool PACKED,
+          bool DB = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelArgs a) {
     constexpr int KK = KS * KS;
     constexpr int BM = 32 * TM * WM;
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     constexpr int NW = (W_VEC4 + NT - 1) / NT;       // float4 weight loads per thread per stage
     constexpr int NX = (X_FLOATS + NT - 1) / NT;     // input loads per thread per stage
 
+    constexpr int STAGE = W_FLOATS + X_FLOATS;     // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Wl = lds;
     float *Xl = lds + W_FLOATS;
@@ -132,16 +137,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
 #pragma unroll
         for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](int buf) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int f = tid + n * NT;
-            if (NW * NT == W_VEC4 || f < W_VEC4) reinterpret_cast<u32x4 *>(Wl)[f] = wreg[n];
+            if (NW * NT == W_VEC4 || f < W_VEC4)
+                reinterpret_cast<u32x4 *>(Wl + buf * STAGE)[f] = wreg[n];
         }
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
             const int e = tid + n * NT;
-            if (NX * NT == X_FLOATS || e < X_FLOATS) reinterpret_cast<unsigned *>(Xl)[e] = xreg[n];
+            if (NX * NT == X_FLOATS || e < X_FLOATS)
+                reinterpret_cast<unsigned *>(Xl + buf * STAGE)[e] = xreg[n];
         }
     };
 
@@ -164,16 +171,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     // operands of k-step s (a pair of input channels q, tap t)
     constexpr int NS = (KC / 2) * KK;
     static_assert(NS % 2 == 0, "k-steps are software-pipelined in pairs");
+    const float *wlc = wl, *xlc = Xl;              // operand bases of the stage being multiplied
     auto load_a = [&](int s, float (&av)[TM]) {
         const int q = s / KK, t = s % KK;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = wl[((2 * q) * KK + t) * BM + i * 32];
+        for (int i = 0; i < TM; ++i) av[i] = wlc[((2 * q) * KK + t) * BM + i * 32];
     };
     auto load_b = [&](int s, float (&bv)[TN]) {
         const int q = s / KK, t = s % KK;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            bv[j] = Xl[(2 * q) * (XR * XC) + (t / KS) * XC + (t % KS) + xoff[j]];
+            bv[j] = xlc[(2 * q) * (XR * XC) + (t / KS) * XC + (t % KS) + xoff[j]];
     };
     auto multiply = [&](const float (&av)[TM], const float (&bv)[TN]) {
 #pragma unroll
@@ -184,37 +192,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     };
 
     load_stage(0);
-    store_stage();
+    store_stage(0);
     __syncthreads();
 
+    constexpr int S_STORE = ((NS * 5 / 8) / 2) * 2;   // k-step before which the idle stage is filled
+    int cur = 0;
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         const bool more = chunk + 1 < a.n_chunks;
         if (more) load_stage(chunk + 1);
-        // two operand register sets: the LDS reads of step s+1 are issued before the MFMAs of
-        // step s, so their latency hides behind 8 x 64 cycles of matrix work
-        float a0[TM], b0[TN], a1[TM], b1[TN];
-        load_a(0, a0);
-        load_b(0, b0);
+        if (DB) {
+            wlc = wl + cur * STAGE;
+            xlc = Xl + cur * STAGE;
+        }
+        // A ring of R operand register sets: the LDS reads of step s+R-1 are issued before the
+        // MFMAs of step s, so their latency hides behind (R-1) x TM*TN x 64 cycles of matrix
+        // work.  sched_barrier pins that order: without it the scheduler sinks each read to
+        // just before its first use and the wave stalls on LDS latency every k-step.
+        constexpr int R = 2;   // deeper rings measured no faster (small tiles) or slower (VGPRs)
+        float av[R][TM], bv[R][TN];
 #pragma unroll
-        for (int s = 0; s < NS; s += 2) {
-            // sched_barrier pins "reads of step s+1, then MFMAs of step s": without it the
-            // scheduler sinks each read to just before its first use and stalls on LDS latency
-            load_a(s + 1, a1);
-            load_b(s + 1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            multiply(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < NS) {
-                load_a(s + 2, a0);
-                load_b(s + 2, b0);
+        for (int d = 0; d < R - 1; ++d) {
+            load_a(d, av[d]);
+            load_b(d, bv[d]);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (DB && s == S_STORE && more) {
+                store_stage(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s + R - 1 < NS) {
+                load_a(s + R - 1, av[(s + R - 1) % R]);
+                load_b(s + R - 1, bv[(s + R - 1) % R]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            multiply(a1, b1);
+            multiply(av[s % R], bv[s % R]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        if (more) {
-            store_stage();
+        if (DB) {
+            cur ^= 1;
+        } else if (more) {
+            store_stage(0);
             __syncthreads();
         }
     }
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
 // Instantiation table
 // ------------------------------------------------------------------------------------------------
 struct ConvVariant {
-    int ks, kc, tm, tn, wm, wn, pr, pc;
+    int ks, kc, tm, tn, wm, wn, pr, pc, db;
 };
 
 static const ConvVariant kVariants[] = {
@@ -293,6 +312,9 @@ static const ConvVariant kVariants[] = {
     /*6*/ {1, 16, 2, 4, 2, 2, 8, 32},  // 1x1, BM 128 : style-gradient product, C >= 128
     /*7*/ {1, 16, 2, 4, 1, 4, 8, 64},  // 1x1, BM  64 : style-gradient product, C == 64
     /*8*/ {3, 4, 2, 1, 1, 4, 4, 32},   // BM  64 x 128 px, KC 4 : first layer, small tiles
+    /*9*/ {3, 8, 2, 1, 1, 4, 4, 32, 1},   // BM 64 x 128 px, two LDS stages
+    /*10*/ {3, 4, 2, 1, 1, 4, 4, 32, 1},  // BM 64 x 128 px, KC 4, two LDS stages
+    /*11*/ {3, 8, 2, 2, 1, 4, 8, 32, 1},  // BM 64 x 256 px, two LDS stages
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -306,7 +328,7 @@ static ConvConfig make_config(int id) {
     c.pc = v.pc;
     c.threads = 64 * v.wm * v.wn;
     const int kk = v.ks * v.ks;
-    c.lds_bytes = sizeof(float) * ((size_t)v.kc * kk * c.bm +
+    c.lds_bytes = sizeof(float) * (1 + v.db) * ((size_t)v.kc * kk * c.bm +
                                    (size_t)v.kc * (v.pr + v.ks - 1) * (v.pc + v.ks - 1));
     return c;
 }
@@ -326,7 +348,8 @@ ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
     if (M <= 32) return make_config(3);
     if (const char *force = getenv("STX_CONV_FORCE")) {   // tuning aid: force one tile config
         const int id = atoi(force);
-        if (id >= 0 && id <= 5 && id != 3 && id != 4) return make_config(id);
+        if (id >= 0 && id <= 11 && id != 3 && id != 4 && id != 6 && id != 7 && id != 8)
+            return make_config(id);
     }
     // Static default (the engine autotunes per shape on top of this): measured on MI355X, many
     // small workgroups beat few large ones because co-resident workgroups run out of phase and
@@ -379,11 +402,13 @@ int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int k
     return STX_OK;
 }
 
-#define STX_CONV_VARIANT(ID, KS, KC, TM, TN, WM, WN, PR, PC)                                      \
+#define STX_CONV_VARIANT(ID, KS, KC, TM, TN, WM, WN, PR, PC) \
+    STX_CONV_VARIANT_DB(ID, KS, KC, TM, TN, WM, WN, PR, PC, false)
+#define STX_CONV_VARIANT_DB(ID, KS, KC, TM, TN, WM, WN, PR, PC, DBUF)                             \
     template <int EPI, bool PACKED>                                                               \
     static int launch_##ID(hipStream_t s, const ConvConfig &cfg, const ConvKernelArgs &args,      \
                            int n_wg) {                                                            \
-        auto kern = conv_mfma_kernel<KS, KC, TM, TN, WM, WN, PR, PC, EPI, PACKED>;                \
+        auto kern = conv_mfma_kernel<KS, KC, TM, TN, WM, WN, PR, PC, EPI, PACKED, DBUF>;          \
         if (cfg.lds_bytes > 64 * 1024) {                                                          \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
@@ -408,6 +433,9 @@ STX_CONV_VARIANT(5, 3, 8, 2, 1, 1, 4, 4, 32)
 STX_CONV_VARIANT(6, 1, 16, 2, 4, 2, 2, 8, 32)
 STX_CONV_VARIANT(7, 1, 16, 2, 4, 1, 4, 8, 64)
 STX_CONV_VARIANT(8, 3, 4, 2, 1, 1, 4, 4, 32)
+STX_CONV_VARIANT_DB(9, 3, 8, 2, 1, 1, 4, 4, 32, true)
+STX_CONV_VARIANT_DB(10, 3, 4, 2, 1, 1, 4, 4, 32, true)
+STX_CONV_VARIANT_DB(11, 3, 8, 2, 2, 1, 4, 8, 32, true)
 
 int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     const ConvVariant &v = kVariants[cfg.id];
@@ -476,6 +504,9 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
         STX_DISPATCH_NOINJ(3)
         STX_DISPATCH_NOINJ(4)
         STX_DISPATCH_NOINJ(8)
+        STX_DISPATCH(9)
+        STX_DISPATCH(10)
+        STX_DISPATCH(11)
         STX_DISPATCH(5)
         STX_DISPATCH_SYMM(6)
         STX_DISPATCH_SYMM(7)
