@@ -175,6 +175,18 @@ int stx_image_cut_tile(stx_engine *e, const float *img, int H, int W, const int 
 int stx_image_put_tile(stx_engine *e, float *grad, int H, int W, const int roll_xy[2],
                        int y0, int x0, int th, int tw, const float *tile_grad);
 
+/* Feature-map preprocessing on the device (eval_features_once / prepare_features,
+ * style_transfer.py:429-486), so that per-scale targets never visit the host:
+ * stx_map_place puts one tile's [C][h][w] map into the full-image map [C][dst_h][dst_w] at
+ * (y0, x0) (the stitch at style_transfer.py:457-461); stx_map_roll_add does one pass of the
+ * rolled-tiling average (style_transfer.py:476-485) on [C][h][w] maps:
+ * init_divisor != 0:  acc  = roll2(src, roll_xy) / init_divisor   (features = feats / passes)
+ * init_divisor == 0:  acc += alpha * roll2(src, roll_xy)          (saxpy(1 / passes, ...)) */
+int stx_map_place(stx_engine *e, float *dst, int channels, int dst_h, int dst_w, int y0, int x0,
+                  const float *src, int h, int w);
+int stx_map_roll_add(stx_engine *e, float *acc, const float *src, int channels, int h, int w,
+                     const int roll_xy[2], double alpha, double init_divisor);
+
 /* TV + p-norm + auxiliary-image terms of eval_loss_and_grad (style_transfer.py:709-733,
  * num_utils.py:74-82,150-162): grad += tv_scale*d tv_norm(img/127.5, tv_power)
  *                                    + p_scale*d p_norm((img+mean-127.5)/127.5, p_power)

@@ -165,6 +165,10 @@ int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int r
                     int th, int tw, float *tile);
 int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, int y0, int x0,
                     int th, int tw, const float *tile);
+int place_window_launch(hipStream_t s, float *dst, int dh, int dw, int y0, int x0, const float *src,
+                        int C, int h, int w);
+int roll_add_launch(hipStream_t s, float *acc, const float *src, int C, int h, int w, int sx, int sy,
+                    float alpha, bool init);
 int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
                         const float mean[3], float tv_scale, float tv_power, float p_scale,
                         float p_power, const float *aux, float aux_scale, double *loss_terms /*[3]*/,

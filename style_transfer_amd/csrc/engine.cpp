@@ -224,8 +224,8 @@ int alloc_dscalars(stx_engine *e, size_t n, size_t *index) {
 int copy_in(stx_engine *e, void *dst, const void *src, int mem, size_t bytes) {
     if (mem == STX_HOST)
         STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
-    else
-        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, e->stream));
+    else   // the source may live on another GPU of the node (peer copy over xGMI)
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
     return STX_OK;
 }
 
@@ -233,7 +233,7 @@ int copy_out(stx_engine *e, void *dst, int mem, const void *src, size_t bytes) {
     if (mem == STX_HOST)
         STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
     else
-        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, e->stream));
+        STX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
     return STX_OK;
 }
 
@@ -1123,6 +1123,27 @@ int stx_image_put_tile(stx_engine *e, float *grad, int H, int W, const int roll_
     STX_TRY(e->set_device());
     return put_tile_launch(e->stream, grad, H, W, roll_xy ? roll_xy[0] : 0,
                            roll_xy ? roll_xy[1] : 0, y0, x0, th, tw, tile_grad);
+}
+
+int stx_map_place(stx_engine *e, float *dst, int channels, int dst_h, int dst_w, int y0, int x0,
+                  const float *src, int h, int w) {
+    if (!e || !dst || !src || channels <= 0 || h <= 0 || w <= 0 || y0 < 0 || x0 < 0 ||
+        y0 + h > dst_h || x0 + w > dst_w) {
+        set_error("stx_map_place: window [%d+%d, %d+%d] does not fit a %dx%d map", y0, h, x0, w,
+                  dst_h, dst_w);
+        return STX_ERR_ARG;
+    }
+    STX_TRY(e->set_device());
+    return place_window_launch(e->stream, dst, dst_h, dst_w, y0, x0, src, channels, h, w);
+}
+
+int stx_map_roll_add(stx_engine *e, float *acc, const float *src, int channels, int h, int w,
+                     const int roll_xy[2], double alpha, double init_divisor) {
+    if (!e || !acc || !src || channels <= 0 || h <= 0 || w <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const bool init = init_divisor != 0.0;
+    return roll_add_launch(e->stream, acc, src, channels, h, w, roll_xy ? roll_xy[0] : 0,
+                           roll_xy ? roll_xy[1] : 0, (float)(init ? init_divisor : alpha), init);
 }
 
 int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,

@@ -102,6 +102,60 @@ int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, in
     return STX_OK;
 }
 
+// ------------------------------------------------------- feature-map stitching on the device ---
+// dst[c][y0 + y][x0 + x] = src[c][y][x]: places one tile's feature map into the full-image map
+// (the stitch of eval_features_once, style_transfer.py:457-461).
+__global__ __launch_bounds__(256) void place_window_kernel(float *__restrict__ dst, int dh, int dw,
+                                                           int y0, int x0,
+                                                           const float *__restrict__ src, int C,
+                                                           int h, int w) {
+    const size_t total = (size_t)C * h * w;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % w;
+        const int y = (i / w) % h;
+        const int c = i / ((size_t)w * h);
+        dst[((size_t)c * dh + y0 + y) * dw + x0 + x] = src[i];
+    }
+}
+
+int place_window_launch(hipStream_t s, float *dst, int dh, int dw, int y0, int x0, const float *src,
+                        int C, int h, int w) {
+    const size_t total = (size_t)C * h * w;
+    place_window_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
+        dst, dh, dw, y0, x0, src, C, h, w);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// acc (= | +=) alpha * roll2(src, (sx, sy)): one pass of prepare_features' averaging
+// (style_transfer.py:479-485) without physically rolling the accumulator back and forth.
+template <bool INIT>
+__global__ __launch_bounds__(256) void roll_add_kernel(float *__restrict__ acc,
+                                                       const float *__restrict__ src, int C, int h,
+                                                       int w, int sx, int sy, float alpha) {
+    const size_t total = (size_t)C * h * w;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % w;
+        const int y = (i / w) % h;
+        const int c = i / ((size_t)w * h);
+        const float v = src[((size_t)c * h + wrap(y - sy, h)) * w + wrap(x - sx, w)];
+        acc[i] = INIT ? v / alpha : alpha * v + acc[i];   // first pass divides (feats / passes)
+    }
+}
+
+// init: acc = roll(src) / alpha;  otherwise acc += alpha * roll(src)
+int roll_add_launch(hipStream_t s, float *acc, const float *src, int C, int h, int w, int sx, int sy,
+                    float alpha, bool init) {
+    const size_t total = (size_t)C * h * w;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (init)
+        roll_add_kernel<true><<<blocks, 256, 0, s>>>(acc, src, C, h, w, sx, sy, alpha);
+    else
+        roll_add_kernel<false><<<blocks, 256, 0, s>>>(acc, src, C, h, w, sx, sy, alpha);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
 // --------------------------------------------------------------------------- regularizers ---
 struct RegArgs {
     const float *img;

@@ -219,6 +219,38 @@ class TileEngine:
         self.sync()
         return dict(zip(layers, outs))
 
+    def features_tile_device(self, img, layers, out=None):
+        """Like features_tile, but the maps stay on the GPU: {layer: DeviceArray}.  ``out`` may
+        supply the destination arrays (reused across tiles).  Asynchronous."""
+        ptr, mem, keep = _as_arg(img)
+        th, tw = keep.shape[-2:]
+        if out is None:
+            out = {}
+        for l in layers:
+            shape = self.feature_shape(l, th, tw)
+            if l not in out or out[l].shape != shape:
+                out[l] = self.empty(shape)
+        names = (ctypes.c_char_p * len(layers))(*[l.encode() for l in layers])
+        ptrs = (ctypes.c_void_p * len(layers))(*[out[l].ptr for l in layers])
+        lib.call('stx_features_tile', self.handle, ptr, mem, th, tw, names, len(layers), ptrs,
+                 lib.DEVICE)
+        if mem == lib.HOST:
+            self.sync()
+        return out
+
+    def map_place(self, dst, y0, x0, src):
+        """dst[:, y0:y0+h, x0:x0+w] = src on the device (feature-map stitch)."""
+        c, h, w = src.shape
+        lib.call('stx_map_place', self.handle, dst.ptr, c, dst.shape[1], dst.shape[2], int(y0),
+                 int(x0), src.ptr, h, w)
+
+    def map_roll_add(self, acc, src, roll_xy, alpha, init_divisor=0.0):
+        """acc = roll2(src, roll_xy) / init_divisor, or acc += alpha * roll2(src, roll_xy)."""
+        c, h, w = src.shape
+        roll = (ctypes.c_int * 2)(int(roll_xy[0]), int(roll_xy[1]))
+        lib.call('stx_map_roll_add', self.handle, acc.ptr, src.ptr, c, h, w, roll, float(alpha),
+                 float(init_divisor))
+
     # --------------------------------------------------------------------------- SCGradRequest
     def _taps(self, content_layers, style_layers, layer_weights, content_weight, style_weight):
         names = list(dict.fromkeys(list(content_layers) + list(style_layers)))

@@ -127,6 +127,60 @@ class TileFarm:
                 self._roll_host(f, -xy * 32 // self.layer_info(layer)[0])
         return feats
 
+    def prepare_features_device(self, img, layers, tile_size=512, passes=10):
+        """prepare_features with everything on the master GPU: the image is uploaded once, tiles
+        are cut with the roll as an index offset, tile maps are stitched by stx_map_place and a
+        pass is folded into the average by stx_map_roll_add (acc += roll(feats, -shift) / passes,
+        which is the reference's roll-accumulate-unroll of the accumulator, bit for bit).
+        Returns {layer: DeviceArray}.  Same RNG draws as the reference."""
+        eng = self.master
+        img = np.ascontiguousarray(img, np.float32)
+        hw = np.array(img.shape[-2:])
+        if max(hw) <= tile_size:
+            passes = 1
+        d_img = eng.to_device(img)
+        rects = tile_grid(hw, tile_size)
+        if len(rects) > 1 and self.verbose:
+            nx = (hw[1] - 1) // tile_size + 1
+            print('Using %dx%d tiles of size %dx%d (x %d passes).' %
+                  (nx, len(rects) // nx, rects[0][3] - rects[0][2], rects[0][1] - rects[0][0],
+                   passes))
+        full, acc = {}, {}
+        for layer in layers:
+            scale, ch = self.layer_info(layer)
+            shape = (ch,) + tuple(int(v) for v in np.int32(np.ceil(hw / scale)))
+            full[layer] = eng.empty(shape).zero()
+            acc[layer] = eng.empty(shape)
+        tiles, tile_feats = {}, {}
+        for i in range(passes):
+            xy = np.array((0, 0))
+            if i > 0:
+                xy = np.int32(np.random.uniform(size=2) * hw) // 32
+            shift = xy * 32
+            for rect in rects:
+                th, tw = rect[1] - rect[0], rect[3] - rect[2]
+                if (th, tw) not in tiles:
+                    tiles[(th, tw)] = eng.empty((3, th, tw))
+                    tile_feats[(th, tw)] = {}
+                tile = tiles[(th, tw)]
+                image_ops.cut_tile(eng, d_img, shift, rect, tile)
+                feats = eng.features_tile_device(tile, list(layers), tile_feats[(th, tw)])
+                for layer in layers:
+                    scale, _ = self.layer_info(layer)
+                    eng.map_place(full[layer], rect[0] // scale, rect[2] // scale, feats[layer])
+            for layer in layers:
+                scale, _ = self.layer_info(layer)
+                back = -(shift // scale)
+                eng.map_roll_add(acc[layer], full[layer], back, 1 / passes,
+                                 init_divisor=passes if i == 0 else 0.0)
+        eng.sync()
+        for bufs in list(tile_feats.values()):
+            for b in bufs.values():
+                b.free()
+        for b in list(tiles.values()) + list(full.values()) + [d_img]:
+            b.free()
+        return acc
+
     @staticmethod
     def _roll_host(arr, xy):
         """roll2 (num_utils.py:136-140): xy[0] shifts the last axis, xy[1] the one before."""

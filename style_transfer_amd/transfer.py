@@ -133,10 +133,11 @@ class StyleTransfer:
                         print('Processing style {} at {}x{}.'.format(i + 1, *scaled.size))
                     else:
                         scaled = image
-                    feats = farm.prepare_features(self.pil_to_image(scaled), style_layers,
-                                                  args.tile_size, passes=1)
+                    feats = farm.prepare_features_device(self.pil_to_image(scaled), style_layers,
+                                                         args.tile_size, passes=1)
                     for layer, feat in feats.items():
                         gram = farm.gram_matrix(feat)
+                        feat.free()
                         grams[layer] = gram if layer not in grams else grams[layer] + gram
                     count += 1
             for gram in grams.values():
@@ -144,8 +145,8 @@ class StyleTransfer:
             self.styles.append(grams)
         print('Preprocessing the content image(s)...')
         for image in content_images:
-            self.contents.append(farm.prepare_features(self.pil_to_image(image), content_layers,
-                                                       args.tile_size, passes=10))
+            self.contents.append(farm.prepare_features_device(
+                self.pil_to_image(image), content_layers, args.tile_size, passes=10))
 
     # ------------------------------------------------------------------------------ objective
     def eval_loss_and_grad(self, params, sc_args):
@@ -178,6 +179,10 @@ class StyleTransfer:
 
         content_layers, content_weight = parse_weights(args.content_layers, args.content_weight)
         style_layers, style_weight = parse_weights(args.style_layers, 1)
+        for content in self.contents:          # device-resident maps of the previous scale
+            for feat in content.values():
+                if hasattr(feat, 'free'):
+                    feat.free()
         self.contents = []
         if not args.style_multiscale:
             self.styles = []

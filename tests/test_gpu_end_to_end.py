@@ -46,3 +46,24 @@ def test_transfer_multiscale_matches_reference_run(golden):
     assert np.abs(u8.astype(int) - golden['e2e.final_u8'].astype(int)).max() <= 1
     assert farm.tile_evals == 4 * 3 + 4 * 2
     farm.close()
+
+
+def test_device_preprocessing_equals_host_stitching():
+    """prepare_features on the GPU (cut with roll offset, stx_map_place, stx_map_roll_add) must be
+    bit-identical to the host-stitched version that mirrors the reference line by line."""
+    net = builtin_net('vgg16_avgpool')
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    rng = np.random.RandomState(2)
+    img = rng.uniform(-110, 120, (3, 150, 130)).astype(np.float32)
+    layers = ['conv1_1', 'conv4_2', 'pool2']
+    np.random.seed(77)
+    host = farm.prepare_features(img, layers, tile_size=64, passes=4)
+    np.random.seed(77)
+    dev = farm.prepare_features_device(img, layers, tile_size=64, passes=4)
+    for layer in layers:
+        got = dev[layer].get()
+        assert got.shape == host[layer].shape
+        assert np.array_equal(got, host[layer]), layer
+    # Gram of a device-resident map == Gram of the same map on the host
+    assert np.array_equal(farm.gram_matrix(dev['conv1_1']), farm.gram_matrix(host['conv1_1']))
+    farm.close()
