@@ -55,6 +55,19 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
+def measured_traffic():
+    """HBM bytes per stx_sc_grad_tile launch from the PMC passes of this build
+    (profiles/r01_c_hbm_traffic_pmc.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    separate runs of this script, FETCH_SIZE doubled per the gfx950 calibration on the Adam
+    kernel -- tools/pmc_traffic.py).  None if the file is missing."""
+    path = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic_pmc.json')
+    try:
+        with open(path) as f:
+            return float(json.load(f)['hbm_bytes_per_tile_iteration'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(net):
     """Times the oracle's tile evaluation on the host cores (checker used as a yardstick only)."""
     from oracle.caffe_net import synthetic_weights
@@ -263,7 +276,7 @@ def main():
                        'tiles_per_step': tiles_per_step, 'final_loss': loss},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                         'traffic': None,
+                         'traffic': measured_traffic(), 'traffic_unit': 'bytes per launch',
                          'kernel': 'stx_sc_grad_tile (conv_mfma_kernel fwd/dgrad/SYMM + gram)',
                          'flop_per_launch': flop, 'avg_launch_ms': tile_avg_ms},
         }

@@ -41,6 +41,7 @@ struct ConvKernelArgs {
     int K, M, H, W;
     int n_chunks;          // ceil(K / KC)
     int tiles_x, tiles_y;  // pixel tiles
+    int m_tiles;           // output-channel tiles
     int w_row_stride;      // floats between consecutive k rows of the weight source
     int w_tile_stride;     // floats between consecutive output-channel tiles (packed mode)
     int x_bytes, w_bytes;  // sizes of the x and w buffers (hardware bounds check of the loads)
@@ -85,9 +86,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int n_ptiles = a.tiles_x * a.tiles_y;
-    const int ptile = blockIdx.x % n_ptiles;
-    const int mtile = blockIdx.x / n_ptiles;
+    // XCD-aware work order.  The dispatcher places workgroup b on XCD b % 8, each with a private
+    // L2.  Logical work item L = (pixel tile, channel tile) with the channel tile fastest, and
+    // every XCD gets a contiguous range of L: all channel tiles of one pixel patch run back to
+    // back on ONE XCD, so the input patch is fetched from HBM once instead of once per channel
+    // tile (placement only affects speed, never results).
+    const int m_tiles = a.m_tiles;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int ptile = L / m_tiles;
+    const int mtile = L - ptile * m_tiles;
     const int y0 = (ptile / a.tiles_x) * PR;
     const int x0 = (ptile % a.tiles_x) * PC;
     const int m0 = mtile * BM;
@@ -458,6 +467,7 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     a.n_chunks = ceil_div(p.K, cfg.kc);
     a.tiles_x = ceil_div(p.W, cfg.pc);
     a.tiles_y = ceil_div(p.H, cfg.pr);
+    a.m_tiles = ceil_div(p.M, cfg.bm);
     a.w_row_stride = packed ? cfg.bm : p.M;
     a.w_tile_stride = packed ? a.n_chunks * cfg.kc * p.ksize * p.ksize * cfg.bm : 0;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
