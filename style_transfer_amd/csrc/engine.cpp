@@ -163,7 +163,7 @@ struct stx_engine {
 
 namespace {
 
-constexpr size_t kScalarFloats = 1 << 16;   // per-call scalar arena (sums + small partials)
+constexpr size_t kScalarFloats = 1 << 18;   // per-call scalar arena (sums + small partials)
 
 // RAII timing of one launch group when profiling is on (no-op otherwise).
 struct ProfScope {
@@ -827,6 +827,16 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     }
     STX_TRY(e->set_device());
     const int rx = roll_xy ? roll_xy[0] : 0, ry = roll_xy ? roll_xy[1] : 0;
+    // the scalar arena holds the reductions of every call queued since the last stx_sync; drain
+    // it (publishing the pending losses) before it could overflow
+    {
+        const size_t per_call = (size_t)n_taps * 2100 * (size_t)std::max(1, e->n_contents + e->n_styles);
+        if (e->scalars_used + per_call > e->scalars_cap) STX_TRY(do_sync(e));
+        if (per_call > e->scalars_cap) {
+            set_error("stx_sc_grad_tile: %d taps need more scalar space than the arena holds", n_taps);
+            return STX_ERR_NOMEM;
+        }
+    }
 
     // ---- taps in deep -> shallow order (style_transfer.py:231-233)
     struct Tap {
