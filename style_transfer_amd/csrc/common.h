@@ -54,7 +54,8 @@ enum ConvEpilogue {
     kEpiForward = 0,      // y = [relu](acc + bias)
     kEpiDgrad = 1,        // y = acc * (mask > 0)      (mask optional)
     kEpiSymm = 2,         // y = acc, plus per-workgroup sum|y| partials
-    kEpiDgradInject = 3   // kEpiDgrad plus the loss-gradient terms of the produced blob (internal)
+    kEpiDgradInject = 3,  // kEpiDgrad plus the loss-gradient terms of the produced blob (internal)
+    kEpiPartial = 4       // raw accumulators of one K slice (split-K, internal)
 };
 
 struct ContentWindow {
@@ -88,6 +89,8 @@ struct ConvProblem {
     int relu;              // kEpiForward
     int epilogue;
     ConvInject inject;     // kEpiDgrad, optional
+    float *splitk_ws = nullptr;      // scratch for split-K partial sums (optional)
+    size_t splitk_ws_floats = 0;
 };
 
 // Tile configuration chosen for a problem; weights must be packed for the same (bm, kc).
@@ -110,6 +113,11 @@ size_t conv_packed_floats(const ConvConfig &cfg, int K, int M, int ksize);
 int conv_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int ksize,
                       int transpose_flip, const ConvConfig &cfg, float *packed);
 int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
+// Number of K slices conv_launch will use for this problem (1 = no split) and the scratch floats
+// that requires.  Small planes yield fewer workgroups than the chip has CUs; slicing the
+// reduction over several workgroups and adding the slices in a fixed order fills the machine.
+int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
+size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);

@@ -42,6 +42,7 @@ struct ConvKernelArgs {
     int n_chunks;          // ceil(K / KC)
     int tiles_x, tiles_y;  // pixel tiles
     int m_tiles;           // output-channel tiles
+    int ksplit;            // K slices (kEpiPartial); 1 otherwise
     int w_row_stride;      // floats between consecutive k rows of the weight source
     int w_tile_stride;     // floats between consecutive output-channel tiles (packed mode)
     int x_bytes, w_bytes;  // sizes of the x and w buffers (hardware bounds check of the loads)
@@ -95,8 +96,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q = nb >> 3, r8 = nb & 7;
     const int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-    const int ptile = L / m_tiles;
-    const int mtile = L - ptile * m_tiles;
+    const int kslice = EPI == kEpiPartial ? L % a.ksplit : 0;
+    const int Lt = EPI == kEpiPartial ? L / a.ksplit : L;
+    const int ptile = Lt / m_tiles;
+    const int mtile = Lt - ptile * m_tiles;
+    const int c_begin = EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0;
+    const int c_end = EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks;
     const int y0 = (ptile / a.tiles_x) * PR;
     const int x0 = (ptile % a.tiles_x) * PC;
     const int m0 = mtile * BM;
@@ -200,14 +205,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     };
 
-    load_stage(0);
+    load_stage(c_begin);
     store_stage(0);
     __syncthreads();
 
     constexpr int S_STORE = ((NS * 5 / 8) / 2) * 2;   // k-step before which the idle stage is filled
     int cur = 0;
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-        const bool more = chunk + 1 < a.n_chunks;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const bool more = chunk + 1 < c_end;
         if (more) load_stage(chunk + 1);
         if (DB) {
             wlc = wl + cur * STAGE;
@@ -270,6 +275,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
                 if (in_img && m < a.M) {
                     const long idx = (long)m * HW + yy * a.W + xx;
                     float v = acc[i][j][r];
+                    if (EPI == kEpiPartial) {
+                        a.y[(long)kslice * a.M * HW + idx] = v;
+                        continue;
+                    }
                     if (EPI == kEpiForward) {
                         if (a.bias) v += a.bias[m];
                         if (a.relu) v = fmaxf(v, 0.f);
@@ -446,6 +455,57 @@ STX_CONV_VARIANT_DB(9, 3, 8, 2, 1, 1, 4, 4, 32, true)
 STX_CONV_VARIANT_DB(10, 3, 4, 2, 1, 1, 4, 4, 32, true)
 STX_CONV_VARIANT_DB(11, 3, 8, 2, 2, 1, 4, 8, 32, true)
 
+// Sums the K slices in a fixed order and applies the epilogue the unsplit kernel would have.
+struct SplitReduceArgs {
+    const float *part;
+    float *y;
+    const float *bias, *mask;
+    ConvInject inj;
+    int ksplit, M, HW, W, relu, epilogue;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
+    const size_t n = (size_t)a.M * a.HW;
+    float s_scale = 0.f, c_scale = 0.f;
+    if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / (float)n + kEps));
+    if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / (float)n + kEps));
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = a.part[i];
+        for (int k = 1; k < a.ksplit; ++k) v += a.part[(size_t)k * n + i];
+        const int m = i / a.HW;
+        if (a.epilogue == kEpiForward) {
+            if (a.bias) v += a.bias[m];
+            if (a.relu) v = fmaxf(v, 0.f);
+        } else {
+            if (a.mask) v = a.mask[i] > 0.f ? v : 0.f;
+            if (a.inj.content) {
+                const int pix = i - (size_t)m * a.HW;
+                v += c_scale * (a.inj.feat[i] -
+                                a.inj.content[content_index(a.inj.win, m, pix / a.W, pix % a.W)]);
+            }
+            if (a.inj.sgrad) v += s_scale * a.inj.sgrad[i];
+        }
+        a.y[i] = v;
+    }
+}
+
+int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
+    if (!packed || p.ksize != 3 || (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad)) return 1;
+    if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;
+    const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
+    const int n_chunks = ceil_div(p.K, cfg.kc);
+    if (n_wg >= 256 || n_chunks < 8) return 1;
+    int f = ceil_div(512, n_wg);
+    f = std::min(f, n_chunks / 4);      // at least four chunks per slice
+    f = std::min(f, 16);
+    return std::max(f, 1);
+}
+
+size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
+    const int f = conv_splitk_factor(cfg, p, packed);
+    return f > 1 ? (size_t)f * p.M * p.H * p.W : 0;
+}
+
 int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     const ConvVariant &v = kVariants[cfg.id];
     if (v.ks != p.ksize) {
@@ -482,11 +542,24 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     a.w_bytes = (int)wb;
     a.relu = p.relu;
     a.inj = p.inject;
+    a.ksplit = 1;
     const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
-    const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
+    int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
+    const int ksplit = conv_splitk_factor(cfg, p, packed);
+    const bool split = ksplit > 1 && p.splitk_ws &&
+                       p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
+    if (split) {
+        a.ksplit = ksplit;
+        a.y = p.splitk_ws;
+        n_wg *= ksplit;
+    }
 
 #define STX_DISPATCH(ID)                                                                          \
     case ID:                                                                                      \
+        if (split) {                                                                              \
+            STX_TRY((launch_##ID<kEpiPartial, true>(s, cfg, a, n_wg)));                           \
+            goto reduce;                                                                          \
+        }                                                                                         \
         if (p.epilogue == kEpiForward && packed)                                                  \
             return launch_##ID<kEpiForward, true>(s, cfg, a, n_wg);                               \
         if (inject && packed) return launch_##ID<kEpiDgradInject, true>(s, cfg, a, n_wg);          \
@@ -527,6 +600,24 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     set_error("conv_launch: no kernel for config %d epilogue %d packed %d", cfg.id, p.epilogue,
               (int)packed);
     return STX_ERR_UNSUPPORTED;
+reduce : {
+    SplitReduceArgs r;
+    r.part = p.splitk_ws;
+    r.y = p.y;
+    r.bias = p.bias;
+    r.mask = p.mask;
+    r.inj = p.inject;
+    r.ksplit = ksplit;
+    r.M = p.M;
+    r.HW = p.H * p.W;
+    r.W = p.W;
+    r.relu = p.relu;
+    r.epilogue = p.epilogue;
+    const size_t n = (size_t)p.M * p.H * p.W;
+    splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, s>>>(r);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
 }
 
 }  // namespace stx

@@ -126,6 +126,7 @@ struct stx_engine {
     std::vector<StyleTarget> styles;
     int n_contents = 0, n_styles = 0;
 
+    DevBuf splitk;                     // split-K partial sums of small-plane convolutions
     DevBuf gram_partials, gram, dsym, symm_partials, upload, img_scratch;
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
@@ -302,6 +303,11 @@ int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig
     const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
     *out = fallback;
     if (!e->autotune || p.ksize != 3 || p.K <= 4 || p.M <= 32) return STX_OK;
+    // planes too small to fill the chip run the small-tile config with a K split that depends on
+    // the shape only (split results differ in rounding from unsplit ones, so no timing here)
+    if (conv_splitk_factor(fallback, p, true) > 1 ||
+        conv_num_workgroups(conv_config_by_id(5), p.M, p.H, p.W) < 256)
+        return STX_OK;
     const std::vector<int> key = {p.ksize, p.K, p.M, p.H, p.W, p.epilogue};
     auto it = e->tuned.find(key);
     if (it != e->tuned.end()) {
@@ -334,6 +340,16 @@ int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig
     return STX_OK;
 }
 
+// Gives the problem a split-K scratch buffer when conv_launch will slice the reduction.
+int attach_splitk(stx_engine *e, const ConvConfig &cfg, ConvProblem &p) {
+    const size_t need = conv_splitk_floats(cfg, p, true);
+    if (!need) return STX_OK;
+    STX_TRY(e->splitk.ensure(need * sizeof(float)));
+    p.splitk_ws = e->splitk.f();
+    p.splitk_ws_floats = e->splitk.bytes / sizeof(float);
+    return STX_OK;
+}
+
 int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     const Layer &L = e->layers[li];
     const Blob &b = e->blobs[L.bottom_blob];
@@ -355,6 +371,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
+    STX_TRY(attach_splitk(e, cfg, p));
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -396,6 +413,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 1, cfg, &packed));
     p.w = packed;
+    STX_TRY(attach_splitk(e, cfg, p));
     ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -630,7 +648,7 @@ void stx_engine_destroy(stx_engine *e) {
     }
     for (auto &c : e->contents) c.feat->release();
     for (auto &s : e->styles) s.gram->release();
-    DevBuf *bufs[] = {&e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
+    DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
                       &e->upload, &e->img_scratch, &e->scalars, &e->dscalars, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
     if (e->scalars_host) (void)hipHostFree(e->scalars_host);
@@ -1278,6 +1296,7 @@ int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, co
     p.ksize = ksize;
     p.relu = relu;
     p.epilogue = kEpiForward;
+    STX_TRY(attach_splitk(e, cfg, p));
     return conv_launch(e->stream, cfg, p, true);
 }
 
@@ -1304,6 +1323,7 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
     p.W = W;
     p.ksize = ksize;
     p.epilogue = kEpiDgrad;
+    STX_TRY(attach_splitk(e, cfg, p));
     return conv_launch(e->stream, cfg, p, true);
 }
 
