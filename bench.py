@@ -6,21 +6,24 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one optimizer iteration of the reference's step loop (style_transfer.py:771-806) at the
-top scale of BASELINE.json's config 2 ("VGG-19 --size 1024 --tile-size 1024, Adam"): draw the
-seam-suppression shift, cut the tile(s), per-tile VGG-19 forward + Gram/content losses + backward
-(stx_sc_grad_tile), stitch, TV + p-norm regularizers, fused Adam step with iterate averaging, step
-statistics.  Everything is resident in HBM when the timed region starts.  Synthetic data: seeded
-He-initialised VGG-19 weights, seeded low-pass-noise content and style pictures (no network).
+top scale of the configuration BASELINE.json's metric is quoted on ("VGG-19 --size 2048 --tile-size
+1024, Adam"): draw the seam-suppression shift, cut the four 1024 x 1024 tiles, per-tile VGG-19
+forward + Gram/content losses + backward (stx_sc_grad_tile; the four tiles run concurrently on four
+HIP streams of the GPU), stitch, TV + p-norm regularizers, fused Adam step with iterate averaging,
+step statistics.  Everything is resident in HBM when the timed region starts.  Synthetic data:
+seeded He-initialised VGG-19 weights, seeded low-pass-noise content and style pictures (no network).
 
-N > 1 is weak scaling: every rank evaluates one 1024 x 1024 tile per step, the image is a grid of
-N such tiles on rank 0 (2048 x 2048 / 1024-px tiles at N = 4 is BASELINE.json's headline config 3);
-tiles go out and gradients come back point-to-point over RCCL, there is no collective on the data
-path.  value = tile-iterations per second of the whole job.
+N > 1 is weak scaling: every rank evaluates four 1024 x 1024 tiles per step and the image grows
+with N (2048 x 4096, 4096 x 4096 -- config 4's top scale -- and 4096 x 8192 at N = 2, 4, 8); rank 0
+owns the image and the optimizer, tiles go out and gradients come back as batched point-to-point
+transfers over RCCL, there is no collective on the data path.  value = tile-iterations per second
+of the whole job.
 
 The line also carries
-  roofline      algorithmic FLOP of one tile-iteration (1 514 240 FLOP per
-                tile pixel) over the GPU time of one stx_sc_grad_tile call, measured with HIP
-                events on the engine's stream inside the timed region, against the fp32 MFMA peak;
+  roofline      algorithmic FLOP of the four tile-iterations of one GPU (SURVEY.md section 8d:
+                1 514 240 FLOP per tile pixel) over the GPU time of that concurrent group of
+                stx_sc_grad_tile calls -- HIP events on each engine's own stream inside the timed
+                region, the longest of the four spans -- against the fp32 MFMA peak;
   cpu_baseline  the numpy oracle (a port of the reference's Caffe-CPU path) timed on this box's
                 host cores on a bounded sample -- rank 0, N = 1 only.
 """
@@ -39,7 +42,8 @@ sys.path.insert(0, REPO)
 TILE = 1024
 FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
-GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+TILES_PER_GPU = 4
+GRIDS = {1: (2, 2), 2: (2, 4), 4: (4, 4), 8: (4, 8)}      # tile grid of the image per world size
 CONTENT_LAYERS = ['conv4_2']
 STYLE_LAYERS = ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
 MEAN = (103.939, 116.779, 123.68)
@@ -62,8 +66,8 @@ def measured_traffic():
     kernel -- tools/pmc_traffic.py).  None if the file is missing."""
     path = os.path.join(REPO, 'profiles', 'r01_c_hbm_traffic_pmc.json')
     try:
-        with open(path) as f:
-            return float(json.load(f)['hbm_bytes_per_tile_iteration'])
+        with open(path) as f:       # measured per tile-iteration; one launch group = 4 of them
+            return float(json.load(f)['hbm_bytes_per_tile_iteration']) * TILES_PER_GPU
     except (OSError, KeyError, ValueError):
         return None
 
@@ -124,127 +128,132 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    from style_transfer_amd import image_ops, lib
-    from style_transfer_amd.engine import TileEngine
-    from style_transfer_amd.farm import tile_grid
+    from style_transfer_amd import image_ops
+    from style_transfer_amd.engine import DeviceArray, TileEngine
+    from style_transfer_amd.farm import TileFarm, tile_grid
     from style_transfer_amd.netspec import builtin_net
     from style_transfer_amd.optimizers import AdamOptimizer
     from style_transfer_amd.weights import synthetic_weights
 
     net = builtin_net('vgg19')
-    eng = TileEngine(net, local_rank, synthetic_weights(net, 0))
+    weights = synthetic_weights(net, 0)
+    # every rank: TILES_PER_GPU engines (HIP streams) on its GPU, one tile of the step each
+    engines = [TileEngine(net, local_rank, weights) for _ in range(TILES_PER_GPU)]
+    eng = engines[0]
     rows, cols = GRIDS[world]
     H, W = rows * TILE, cols * TILE
     rects = tile_grid((H, W), TILE)
+    assert len(rects) == TILES_PER_GPU * world
     content_weight = {'conv4_2': 0.05}
     style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
 
     # ---- targets (once, outside the timed region): style Grams and the content map of the image
     contents, styles = [], []
     if rank == 0:
-        from style_transfer_amd.farm import TileFarm
         helper = TileFarm(net, verbose=False, engines=[eng])
-        style_feats = helper.eval_features_once(smooth_picture(7, TILE, TILE), STYLE_LAYERS, TILE)
+        style_feats = helper.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS,
+                                                     TILE, passes=1)
         styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
-        contents = [helper.eval_features_once(smooth_picture(8, H, W), CONTENT_LAYERS, TILE)]
+        contents = [{l: f.get() for l, f in helper.prepare_features_device(
+            smooth_picture(8, H, W), CONTENT_LAYERS, TILE, passes=1).items()}]
     if world > 1:
         from style_transfer_amd.dist import DistributedTiles, broadcast_targets
         contents, styles = broadcast_targets(contents, styles, device)
-    eng.set_contents_and_styles(contents, styles)
+    for e in engines:
+        e.set_contents_and_styles(contents, styles)
 
-    def wrap(tensor):
+    def wrap(tensor, engine):
         """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
-        from style_transfer_amd.engine import DeviceArray
         arr = DeviceArray.__new__(DeviceArray)
-        arr.engine, arr.shape, arr.dtype = eng, tuple(tensor.shape), np.dtype(np.float32)
+        arr.engine, arr.shape, arr.dtype = engine, tuple(tensor.shape), np.dtype(np.float32)
         arr.nbytes, arr.ptr = tensor.numel() * 4, tensor.data_ptr()
         arr.free = lambda: None
         return arr
 
-    tile_ms = []
+    group_ms = []           # GPU time of one concurrent group of tile evaluations on this rank
     state = {}
     if rank == 0:
         rng = np.random.RandomState(0)
         # the reference's start image: uniform noise minus the mean (style_transfer.py:889)
         img = eng.to_device(rng.uniform(0, 255, (3, H, W)).astype(np.float32) -
                             np.float32(MEAN).reshape(3, 1, 1))
-        grad = eng.empty((3, H, W))
-        old_avg = eng.empty((3, H, W)).copy_from(img)
-        opt = AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
-        state.update(img=img, grad=grad, old=old_avg, opt=opt, rng=np.random.RandomState(0))
+        state.update(img=img, grad=eng.empty((3, H, W)),
+                     old=eng.empty((3, H, W)).copy_from(img), rng=np.random.RandomState(0),
+                     opt=AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05,
+                                       power=0.5))
 
-    if world == 1:
-        tile_buf, tgrad_buf = eng.empty((3, TILE, TILE)), eng.empty((3, TILE, TILE))
+    def evaluate(jobs, roll):
+        """Runs this rank's tiles concurrently, one per engine; [(loss, grad tensor)]."""
+        pend = []
+        for k, (tile, start) in enumerate(jobs):
+            e = engines[k % len(engines)]
+            g = grad_bufs[k]
+            pend.append(e.sc_grad_tile_async(wrap(tile, e), start, roll, CONTENT_LAYERS,
+                                             STYLE_LAYERS, {}, content_weight, style_weight,
+                                             grad_out=wrap(g, e)))
+        used = engines[:min(len(jobs), len(engines))]
+        for e in used:
+            e.sync()
+        group_ms.append(max(e.last_tile_ms() for e in used))
+        return [(p.loss, grad_bufs[k]) for k, p in enumerate(pend)]
 
-        def eval_sc_grad(params, roll):
-            image_ops.cut_tile(eng, params, roll, rects[0], tile_buf)
-            pend = eng.sc_grad_tile_async(tile_buf, (0, 0), roll, CONTENT_LAYERS, STYLE_LAYERS, {},
-                                          content_weight, style_weight, grad_out=tgrad_buf)
-            image_ops.put_tile(eng, state['grad'], roll, rects[0], tgrad_buf)
-            return pend
-    else:
-        send_bufs = {}
+    grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
+                 for _ in range(TILES_PER_GPU)]
+    tile_bufs = {}
 
-        def cut(rect, roll):
-            key = rect
-            if key not in send_bufs:
-                send_bufs[key] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
-                                             dtype=torch.float32, device=device)
-            image_ops.cut_tile(eng, state['img'], roll, rect, wrap(send_bufs[key]))
-            eng.sync()
-            return send_bufs[key]
+    def cut(rect, roll):
+        if rect not in tile_bufs:
+            tile_bufs[rect] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
+                                          dtype=torch.float32, device=device)
+        image_ops.cut_tile(eng, state['img'], roll, rect, wrap(tile_bufs[rect], eng))
+        return tile_bufs[rect]
 
-        grad_t = torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
+    def put(rect, g, roll):
+        image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g, eng))
 
-        def evaluate(tile, start, roll):
-            pend = eng.sc_grad_tile_async(wrap(tile), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {},
-                                          content_weight, style_weight, grad_out=wrap(grad_t))
-            eng.sync()
-            tile_ms.append(eng.last_tile_ms())
-            return pend.loss, grad_t
+    if world > 1:
+        farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0], evaluate, put,
+                                device)
 
-        def put(rect, g, roll):
-            image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g))
-
-        farm = DistributedTiles(cut, evaluate, put, device)
+    def eval_sc_grad(roll):
+        if world > 1:
+            return farm.eval_sc_grad(rects, roll)
+        tiles = [cut(rect, roll) for rect in rects]
+        eng.sync()
+        results = evaluate([(t, (r[0], r[2])) for t, r in zip(tiles, rects)], roll)
+        for rect, (_, g) in zip(rects, results):
+            put(rect, g, roll)
+        return sum(l for l, _ in results)
 
     def step():
-        if rank == 0:
-            xy = np.int32(state['rng'].uniform(-0.5, 0.5, size=2) * (H, W)) // 8
-            roll = xy * 8
-        else:
-            roll = (0, 0)
+        if rank != 0:
+            farm.eval_sc_grad(rects, (0, 0))
+            return None
+        xy = np.int32(state['rng'].uniform(-0.5, 0.5, size=2) * (H, W)) // 8
+        roll = xy * 8
 
         def opfunc(params):
-            if world == 1:
-                pend = eval_sc_grad(params, roll)
-                reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
-                eng.sync()
-                tile_ms.append(eng.last_tile_ms())
-                return pend.loss + reg.value, state['grad']
-            loss = farm.eval_sc_grad(rects, roll)
+            loss = eval_sc_grad(roll)
             reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
             eng.sync()
             return loss + reg.value, state['grad']
-
-        if rank == 0:
-            avg, loss = state['opt'].update(opfunc)
-            image_ops.step_stats(eng, avg, state['old'])
-            return loss
-        farm.eval_sc_grad(rects, roll)
-        return None
+        avg, loss = state['opt'].update(opfunc)
+        image_ops.step_stats(eng, avg, state['old'])
+        return loss
 
     def fence():
-        eng.sync()
+        for e in engines:
+            e.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
+    loss = None
     for _ in range(opts.warmup):
         step()
     fence()
-    tile_ms.clear()
+    group_ms.clear()
     t0 = time.perf_counter()
     for _ in range(opts.steps):
         loss = step()
@@ -258,27 +267,29 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / opts.steps * 1e3
         tiles_per_step = len(rects)
-        tile_avg_ms = float(np.mean(tile_ms))
-        flop = FLOP_PER_TILE_PIXEL * TILE * TILE
-        achieved = flop / (tile_avg_ms * 1e-3) / 1e12
+        avg_group_ms = float(np.mean(group_ms))
+        flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
+        achieved = flop / (avg_group_ms * 1e-3) / 1e12
         line = {
-            'metric': 'tile-iterations/sec, VGG-19 1024px tiles (fwd+bwd, Gram/content losses, '
+            'metric': 'tile-iterations/sec, VGG-19 2048px/1024-tile (fwd+bwd, Gram/content losses, '
                       'regularizers, Adam step)',
             'value': tiles_per_step * opts.steps / elapsed,
             'unit': 'tile-iterations/s',
             'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tile(s) '
-                                   'of %dx%d per step, one per GPU' % (max(H, W), TILE, W, H,
-                                                                      tiles_per_step, TILE, TILE),
+            'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tiles of '
+                                   '%dx%d per step, %d per GPU' % (max(H, W), TILE, W, H, tiles_per_step,
+                                                                 TILE, TILE, TILES_PER_GPU),
                        'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
-                       'tiles_per_step': tiles_per_step, 'final_loss': loss},
+                       'tiles_per_step': tiles_per_step, 'tiles_per_gpu': TILES_PER_GPU,
+                       'final_loss': loss},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'traffic': measured_traffic(), 'traffic_unit': 'bytes per launch',
-                         'kernel': 'stx_sc_grad_tile (conv_mfma_kernel fwd/dgrad/SYMM + gram)',
-                         'flop_per_launch': flop, 'avg_launch_ms': tile_avg_ms},
+                         'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU (conv_mfma_kernel '
+                                   'fwd/dgrad/SYMM + gram)' % TILES_PER_GPU,
+                         'flop_per_launch': flop, 'avg_launch_ms': avg_group_ms},
         }
         if world == 1 and not opts.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(net)
@@ -286,7 +297,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engines:
+        e.close()
 
 
 if __name__ == '__main__':

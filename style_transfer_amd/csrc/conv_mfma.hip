@@ -494,11 +494,20 @@ int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed)
     if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
     const int n_chunks = ceil_div(p.K, cfg.kc);
-    if (n_wg >= 256 || n_chunks < 8) return 1;
-    int f = ceil_div(512, n_wg);
-    f = std::min(f, n_chunks / 4);      // at least four chunks per slice
-    f = std::min(f, 16);
-    return std::max(f, 1);
+    // All workgroups of a launch become resident at once while they fit (about five per CU for
+    // the small-tile configs), so a count that is not a multiple of the 256 CUs leaves the CUs
+    // unevenly loaded for the whole kernel: 552 workgroups run as 3 on some CUs and 2 on others,
+    // 72 % efficient.  Slice K until the load is within 10 % of even or the launch oversubscribes
+    // the chip (then the dispatcher balances dynamically).
+    constexpr int kCUs = 256, kResident = 5 * kCUs;
+    const int max_split = std::min(16, n_chunks / 4);      // at least four chunks per slice
+    for (int f = 1; f <= max_split; ++f) {
+        const int n = n_wg * f;
+        if (n > kResident) return f;
+        const double even = (double)n / kCUs, worst = (double)ceil_div(n, kCUs);
+        if (n >= 2 * kCUs && even / worst >= 0.9) return f;
+    }
+    return std::max(max_split, 1);
 }
 
 size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed) {

@@ -8,15 +8,17 @@ the regularizers, like the reference's parent process); every rank, rank 0 inclu
 worker.  Per evaluation:
 
     rank 0: cut the tiles of the (virtually rolled) image        style_transfer.py:623-637
-    scatter: tile t -> rank t mod world   (point-to-point sends, no collective reduction)
+    scatter: tile t -> rank t mod world   (the reference's round-robin, :284-288)
     all ranks: evaluate their tiles                               style_transfer.py:230-241
     gather: tile gradients and losses -> rank 0
     rank 0: stitch                                                style_transfer.py:639-643
 
-Tiles never exchange data with each other, so the only traffic is 12 bytes per tile pixel in
-each direction.  Targets (style Grams, content maps) are broadcast once per scale with
-``broadcast_targets``.  The arithmetic is injected through three callables so that the
-protocol can be exercised on CPU (gloo) in the unit tests.
+Tiles never exchange data with each other, so there is no collective on the data path: the
+scatter and the gather are batched point-to-point transfers (``batch_isend_irecv``), which on
+RCCL run concurrently over the separate xGMI links from GPU 0 to each peer -- 12 bytes per tile
+pixel each way.  Targets (style Grams, content maps) are broadcast once per scale with
+``broadcast_targets``.  The arithmetic is injected through callables so that the protocol can
+be exercised on CPU (gloo) in the unit tests.
 """
 
 import numpy as np
@@ -25,8 +27,9 @@ import torch.distributed as dist
 
 
 class DistributedTiles:
-    """cut(rect) -> tensor[3,th,tw] on rank 0; evaluate(tile, start_yx, roll) -> (loss, grad
-    tensor) on every rank; put(rect, grad) on rank 0.  All tensors live on ``device``."""
+    """cut(rect, roll) -> tensor[3,th,tw] on rank 0; evaluate(jobs, roll) with
+    jobs = [(tile tensor, (y0, x0)), ...] -> [(loss, grad tensor), ...] on every rank;
+    put(rect, grad, roll) on rank 0.  All tensors live on ``device``."""
 
     def __init__(self, cut, evaluate, put, device, group=None):
         self.cut, self.evaluate, self.put = cut, evaluate, put
@@ -34,10 +37,23 @@ class DistributedTiles:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._recv = {}
 
     def _sync(self):
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
+
+    def _buffer(self, key, shape, dtype=torch.float32):
+        buf = self._recv.get(key)
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            buf = self._recv[key] = torch.empty(shape, dtype=dtype, device=self.device)
+        return buf
+
+    @staticmethod
+    def _run(ops):
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
     def eval_sc_grad(self, rects, roll):
         """rects: the tile grid [(y0,y1,x0,x1)] (identical on all ranks); roll: (x, y) pixel
@@ -47,54 +63,68 @@ class DistributedTiles:
             header[0], header[1] = int(roll[0]), int(roll[1])
         dist.broadcast(header, 0, group=self.group)
         roll = (int(header[0]), int(header[1]))
-        total = 0.0
-        for base in range(0, len(rects), self.world):
-            batch = rects[base:base + self.world]
-            mine = batch[self.rank] if self.rank < len(batch) else None
-            # ---- scatter: rank 0 sends tile r to rank r
-            tile = None
-            if self.rank == 0:
-                sends = []
-                for r, rect in enumerate(batch):
-                    t = self.cut(rect, roll)
-                    if r == 0:
-                        tile = t
-                    else:
-                        sends.append(dist.isend(t.contiguous(), r, group=self.group))
-                self._sync()
-                for s in sends:
-                    s.wait()
-            elif mine is not None:
-                tile = torch.empty((3, mine[1] - mine[0], mine[3] - mine[2]), dtype=torch.float32,
-                                   device=self.device)
-                dist.recv(tile, 0, group=self.group)
+        owner = [t % self.world for t in range(len(rects))]
+        mine = [t for t in range(len(rects)) if owner[t] == self.rank]
+        shape = lambda t: (3, rects[t][1] - rects[t][0], rects[t][3] - rects[t][2])
+
+        # ---- scatter
+        tiles = {}
+        ops = []
+        if self.rank == 0:
+            for t, rect in enumerate(rects):
+                tile = self.cut(rect, roll)
+                if owner[t] == 0:
+                    tiles[t] = tile
+                else:
+                    ops.append(dist.P2POp(dist.isend, tile.contiguous(), owner[t], self.group))
             self._sync()
-            # ---- evaluate
-            loss, grad = (0.0, None)
-            if mine is not None:
-                loss, grad = self.evaluate(tile, (mine[0], mine[2]), roll)
-            # ---- gather
-            if self.rank == 0:
-                if mine is not None:
-                    self.put(mine, grad, roll)
-                    total += loss
-                for r, rect in enumerate(batch):
-                    if r == 0:
-                        continue
-                    buf = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
-                                      dtype=torch.float32, device=self.device)
-                    dist.recv(buf, r, group=self.group)
-                    lbuf = torch.zeros(1, dtype=torch.float64, device=self.device)
-                    dist.recv(lbuf, r, group=self.group)
-                    self._sync()
-                    self.put(rect, buf, roll)
-                    total += float(lbuf[0])
-            elif mine is not None:
-                self._sync()
-                dist.send(grad.contiguous(), 0, group=self.group)
-                dist.send(torch.tensor([loss], dtype=torch.float64, device=self.device), 0,
-                          group=self.group)
-        return total if self.rank == 0 else None
+        else:
+            for t in mine:
+                tiles[t] = self._buffer(('tile', t), shape(t))
+                ops.append(dist.P2POp(dist.irecv, tiles[t], 0, self.group))
+        self._run(ops)
+        self._sync()
+
+        # ---- evaluate the local tiles (possibly concurrently, that is the callee's business)
+        results = self.evaluate([(tiles[t], (rects[t][0], rects[t][2])) for t in mine], roll) \
+            if mine else []
+        self._sync()
+
+        # ---- gather
+        ops = []
+        if self.rank == 0:
+            total = 0.0
+            incoming = []
+            for t in range(len(rects)):
+                if owner[t] == 0:
+                    continue
+                gbuf = self._buffer(('grad', t), shape(t))
+                ops.append(dist.P2POp(dist.irecv, gbuf, owner[t], self.group))
+                incoming.append((t, gbuf))
+            loss_bufs = {r: self._buffer(('loss', r), (sum(1 for o in owner if o == r),),
+                                         torch.float64)
+                         for r in range(1, self.world) if r in owner}
+            for r, lbuf in loss_bufs.items():
+                ops.append(dist.P2POp(dist.irecv, lbuf, r, self.group))
+            self._run(ops)
+            self._sync()
+            for t, (loss, grad) in zip(mine, results):
+                self.put(rects[t], grad, roll)
+                total += loss
+            for t, gbuf in incoming:
+                self.put(rects[t], gbuf, roll)
+            for lbuf in loss_bufs.values():
+                total += float(lbuf.sum())
+            return total
+        if mine:
+            for (loss, grad) in results:
+                ops.append(dist.P2POp(dist.isend, grad.contiguous(), 0, self.group))
+            losses = torch.tensor([loss for loss, _ in results], dtype=torch.float64,
+                                  device=self.device)
+            ops.append(dist.P2POp(dist.isend, losses, 0, self.group))
+            self._run(ops)
+            self._sync()
+        return None
 
 
 def broadcast_targets(contents, styles, device, group=None):
@@ -102,8 +132,8 @@ def broadcast_targets(contents, styles, device, group=None):
     rank = dist.get_rank(group)
     meta = [None]
     if rank == 0:
-        meta[0] = ([{k: v.shape for k, v in c.items()} for c in contents],
-                   [{k: v.shape for k, v in s.items()} for s in styles])
+        meta[0] = ([{k: tuple(v.shape) for k, v in c.items()} for c in contents],
+                   [{k: tuple(v.shape) for k, v in s.items()} for s in styles])
     dist.broadcast_object_list(meta, 0, group=group)
     cshapes, sshapes = meta[0]
     out = []
@@ -113,7 +143,9 @@ def broadcast_targets(contents, styles, device, group=None):
             d = {}
             for layer, shape in shape_map.items():
                 if rank == 0:
-                    t = torch.from_numpy(np.ascontiguousarray(src[i][layer], np.float32)).to(device)
+                    host = src[i][layer]
+                    host = host.get() if hasattr(host, 'get') else host
+                    t = torch.from_numpy(np.ascontiguousarray(host, np.float32)).to(device)
                 else:
                     t = torch.empty(shape, dtype=torch.float32, device=device)
                 dist.broadcast(t, 0, group=group)

@@ -51,11 +51,14 @@ def _worker(rank, world, port, out_path):
     def cut(rect, r):
         return torch.from_numpy(np.ascontiguousarray(rolled[:, rect[0]:rect[1], rect[2]:rect[3]]))
 
-    def evaluate(tile, start, r):
+    def evaluate(jobs, r):
+        out = []
         om.roll_contents(r)
-        loss, g = om.sc_grad_tile(tile.numpy(), start, cl, sl, {}, cw, sw)
+        for tile, start in jobs:
+            loss, g = om.sc_grad_tile(tile.numpy(), start, cl, sl, {}, cw, sw)
+            out.append((loss, torch.from_numpy(g)))
         om.roll_contents((-r[0], -r[1]))
-        return loss, torch.from_numpy(g)
+        return out
 
     def put(rect, g, r):
         grad[:, rect[0]:rect[1], rect[2]:rect[3]] = g.numpy()
