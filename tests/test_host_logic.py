@@ -1,0 +1,119 @@
+"""Host-side logic (no GPU): options, tile geometry, pyramid, weight parsing, model files."""
+
+import ast
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import tile_path
+from style_transfer_amd import config_system, farm, netspec, transfer, weights
+
+
+def test_parse_args_defaults_match_reference(golden):
+    """Every option the reference's parse_args produces exists here with the same default."""
+    ref = dict(ast.literal_eval(str(golden['args.defaults_repr'])))
+    args = config_system.parse_args(None, ['-ci', 'c.png', '-si', 's.png'], config_py=False)
+    mine = {k: str(getattr(args, k)) for k in args}
+    assert set(ref) == set(mine)
+    for key, value in ref.items():
+        assert mine[key] == value, key
+
+
+def test_option_precedence_and_lazy_values(tmp_path):
+    cfg1 = tmp_path / 'config.py'
+    cfg1.write_text('size = 640\ntile_size = 320\ntv_weight = lambda s: 5 / (s.step + 1)\n')
+    cfg2 = tmp_path / 'extra.py'
+    cfg2.write_text('tile_size = 200\ndevices = detect_devices()\n')
+    from argparse import Namespace
+    state = Namespace(step=4)
+    args = config_system.parse_args(state, ['-ci', 'c', '-si', 's', '--size', '300', '--config',
+                                            str(cfg2)], config_py=cfg1)
+    assert args.size == 300          # command line beats config.py
+    assert args.tile_size == 200     # --config file beats everything
+    assert args.tv_weight == 1.0     # callable of the state, evaluated on read
+    state.step = 0
+    assert args.tv_weight == 5.0
+    assert args.devices in ([-1], list(range(len(args.devices))))
+    assert config_system.ffloat('1/4') == 0.25
+
+
+@pytest.mark.parametrize('hw,tile', [((96, 112), 64), ((75, 93), 48), ((2048, 2048), 1024),
+                                     ((2896, 2896), 1024), ((1448, 1448), 1024), ((130, 150), 512),
+                                     ((1024, 768), 512)])
+def test_tile_grid_matches_oracle(hw, tile):
+    rects = farm.tile_grid(hw, tile)
+    assert rects == tile_path.tile_grid(hw, tile)
+    cover = np.zeros(hw, int)
+    for y0, y1, x0, x1 in rects:
+        cover[y0:y1, x0:x1] += 1
+        assert y1 - y0 <= tile + tile // 2 and x1 - x0 <= tile + tile // 2
+    assert np.all(cover == 1)
+
+
+def test_pyramid_and_resize():
+    assert transfer.pyramid_sizes(1024, 182) == [1024, 724, 512, 362, 256]
+    assert transfer.pyramid_sizes(2048, 182) == [2048, 1448, 1024, 724, 512, 362, 256]
+    assert transfer.pyramid_sizes(4096, 182)[:3] == [4096, 2896, 2048]
+    img = Image.new('RGB', (400, 300))
+    assert transfer.resize_to_fit(img, 200).size == (200, 150)
+    assert transfer.resize_to_fit(img, 800).size == (400, 300)            # never up...
+    assert transfer.resize_to_fit(img, 800, scale_up=True).size == (800, 600)   # ...unless asked
+    assert transfer.resize_to_fit(img, 250, div=32).size == (224, 160)
+
+
+def test_parse_weights_normalises_to_master():
+    names, w = transfer.parse_weights(['conv1_1', 'conv2_1:3', 'conv3_1:1/2'], 2.0)
+    assert names == ['conv1_1', 'conv2_1', 'conv3_1']
+    assert sum(abs(v) for v in w.values()) == pytest.approx(2.0)
+    assert w['conv2_1'] == pytest.approx(3 * w['conv1_1'])
+
+
+@pytest.mark.parametrize('legacy', [False, True])
+def test_caffemodel_round_trip(tmp_path, legacy):
+    net = netspec.builtin_net('vgg16')
+    params = weights.synthetic_weights(net, 4)
+    small = {k: params[k] for k in list(params)[:4]}
+    path = str(tmp_path / 'w.caffemodel')
+    weights.write_caffemodel(path, small, legacy=legacy)
+    short = netspec.NetSpec('short', [l for l in net.layers if l.name in
+                                      ('input', 'conv1_1', 'relu1_1', 'conv1_2', 'relu1_2', 'pool1',
+                                       'conv2_1', 'relu2_1', 'conv2_2', 'relu2_2')])
+    loaded = weights.load_weights(path, short)
+    for name, (w, b) in small.items():
+        assert np.array_equal(loaded[name][0], w) and np.array_equal(loaded[name][1], b)
+    with pytest.raises(FileNotFoundError):
+        weights.load_weights(str(tmp_path / 'missing.caffemodel'), short)
+    assert np.array_equal(weights.load_weights('synthetic:4', net)['conv3_1'][0], params['conv3_1'][0])
+
+
+def test_synthetic_weights_agree_with_oracle():
+    from oracle.caffe_net import synthetic_weights as oracle_weights
+    net = netspec.builtin_net('vgg19')
+    a, b = weights.synthetic_weights(net, 0), oracle_weights(net.as_dicts(), 0)
+    assert all(np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]) for k in a)
+
+
+def test_unsupported_options_fail_loudly():
+    from argparse import Namespace
+    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--jitter'], config_py=False)
+
+    class FakeFarm:
+        master = None
+
+        def layers(self):
+            return []
+    with pytest.raises(NotImplementedError):
+        transfer.StyleTransfer(FakeFarm(), args, Namespace())
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under style_transfer_amd/ may import it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'style_transfer_amd')
+    for dirpath, _, files in os.walk(root):
+        for name in files:
+            if name.endswith('.py'):
+                text = open(os.path.join(dirpath, name)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, name
