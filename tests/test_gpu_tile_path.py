@@ -111,7 +111,7 @@ def test_tiled_sc_grad_with_roll_matches_reference_vectors(golden, tag, model):
 
 
 @pytest.mark.parametrize('model', ['vgg19', 'vgg16_avgpool'])
-@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96), (33, 130)])
+@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96), (33, 130), (9, 13), (16, 1)])
 def test_sc_grad_tile_odd_sizes_against_oracle(model, th, tw):
     om, _ = make_oracle(model)
     eng = gpu_engine(model)
@@ -124,7 +124,10 @@ def test_sc_grad_tile_odd_sizes_against_oracle(model, th, tw):
     om.contents = [om.prepare_features(full, cl, 512)]
     eng.set_contents_and_styles(om.contents, om.styles)
     tile = np.ascontiguousarray(full[:, 16:16 + th, 8:8 + tw])
-    check_tile(eng, om, tile, (16, 8), (-16, 24), cl, cw, sl, sw, {}, 'avg' in model)
+    # tiny tiles (deep blobs of 1x1 .. 2x2) have few elements per layer, so one flipped ReLU
+    # decision moves more of the gradient norm: only the same-activations check is tight there
+    check_tile(eng, om, tile, (16, 8), (-16, 24), cl, cw, sl, sw, {},
+               'avg' in model and th * tw > 400)
 
 
 def test_non_default_taps(golden):
