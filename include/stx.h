@@ -187,6 +187,17 @@ int stx_map_place(stx_engine *e, float *dst, int channels, int dst_h, int dst_w,
 int stx_map_roll_add(stx_engine *e, float *acc, const float *src, int channels, int h, int w,
                      const int roll_xy[2], double alpha, double init_divisor);
 
+/* Resampling between pyramid scales (num_utils.resize, num_utils.py:90-108, used by
+ * style_transfer.py:399-401 and optimizers.py:53-61): Pillow's separable 'F'-mode resampler --
+ * horizontal pass, then vertical pass on the float32 intermediate, double accumulation.  The
+ * caller supplies, per axis, the window table bounds[out][2] = (first input index, tap count) and
+ * the normalised weights[out][ksize] (host memory); src [C][H][W] and dst [C][out_h][out_w] are
+ * STX_DEVICE.  clamp_min_zero applies max(0, .) to the result (the Adam g2 state).  Synchronous. */
+int stx_image_resample(stx_engine *e, const float *src, int channels, int H, int W, float *dst,
+                       int out_h, int out_w, const int *bounds_x, const double *weights_x,
+                       int ksize_x, const int *bounds_y, const double *weights_y, int ksize_y,
+                       int clamp_min_zero);
+
 /* TV + p-norm + auxiliary-image terms of eval_loss_and_grad (style_transfer.py:709-733,
  * num_utils.py:74-82,150-162): grad += tv_scale*d tv_norm(img/127.5, tv_power)
  *                                    + p_scale*d p_norm((img+mean-127.5)/127.5, p_power)

@@ -177,6 +177,8 @@ int place_window_launch(hipStream_t s, float *dst, int dh, int dw, int y0, int x
                         int C, int h, int w);
 int roll_add_launch(hipStream_t s, float *acc, const float *src, int C, int h, int w, int sx, int sy,
                     float alpha, bool init);
+int resample_launch(hipStream_t s, int axis, const float *src, int C, int H, int W, float *dst,
+                    int OH, int OW, const int *bounds, const double *k, int ksize, int clamp);
 int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
                         const float mean[3], float tv_scale, float tv_power, float p_scale,
                         float p_power, const float *aux, float aux_scale, double *loss_terms /*[3]*/,

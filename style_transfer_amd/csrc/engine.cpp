@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -137,9 +138,7 @@ struct stx_engine {
     DevBuf red_scratch;                // float partials for image-op reductions
     std::vector<PendingLoss> pending;
 
-    // tile-config autotuning: (ksize, K, M, H, W, epilogue) -> config id, measured once per shape
-    std::map<std::vector<int>, int> tuned;
-    bool autotune = true;
+    bool autotune = true;   // tile-config autotuning (process-wide cache, see choose_conv_config)
 
     // optional per-kernel-group timing (stx_profile_enable): event pairs around launch groups
     bool profiling = false;
@@ -299,6 +298,11 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
 // many workgroups the plane yields (co-resident workgroups hide each other's stage swaps and
 // epilogues).  The first time a shape is seen every candidate is timed with HIP events on the
 // engine stream (a few launches, once per shape and scale) and the winner is cached.
+// The cache is shared by all engines of the process (several engines drive the same GPU as
+// separate streams; they must agree, and later ones need not re-measure).  Key: device + shape.
+static std::mutex g_tuned_mutex;
+static std::map<std::vector<int>, int> g_tuned;
+
 int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out) {
     const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
     *out = fallback;
@@ -308,11 +312,14 @@ int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig
     if (conv_splitk_factor(fallback, p, true) > 1 ||
         conv_num_workgroups(conv_config_by_id(5), p.M, p.H, p.W) < 256)
         return STX_OK;
-    const std::vector<int> key = {p.ksize, p.K, p.M, p.H, p.W, p.epilogue};
-    auto it = e->tuned.find(key);
-    if (it != e->tuned.end()) {
-        *out = conv_config_by_id(it->second);
-        return STX_OK;
+    const std::vector<int> key = {e->device, p.ksize, p.K, p.M, p.H, p.W, p.epilogue};
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mutex);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) {
+            *out = conv_config_by_id(it->second);
+            return STX_OK;
+        }
     }
     const int candidates[] = {0, 1, 2, 5};
     float best_ms = 1e30f;
@@ -335,7 +342,10 @@ int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig
             best = id;
         }
     }
-    e->tuned[key] = best;
+    {
+        std::lock_guard<std::mutex> lock(g_tuned_mutex);
+        g_tuned[key] = best;
+    }
     *out = conv_config_by_id(best);
     return STX_OK;
 }
@@ -1172,6 +1182,38 @@ int stx_map_roll_add(stx_engine *e, float *acc, const float *src, int channels, 
     const bool init = init_divisor != 0.0;
     return roll_add_launch(e->stream, acc, src, channels, h, w, roll_xy ? roll_xy[0] : 0,
                            roll_xy ? roll_xy[1] : 0, (float)(init ? init_divisor : alpha), init);
+}
+
+int stx_image_resample(stx_engine *e, const float *src, int channels, int H, int W, float *dst,
+                       int out_h, int out_w, const int *bounds_x, const double *weights_x,
+                       int ksize_x, const int *bounds_y, const double *weights_y, int ksize_y,
+                       int clamp_min_zero) {
+    if (!e || !src || !dst || !bounds_x || !weights_x || !bounds_y || !weights_y || channels <= 0 ||
+        H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || ksize_x <= 0 || ksize_y <= 0)
+        return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    // device scratch: [bounds_x | bounds_y] ints, [kx | ky] doubles, horizontal-pass image
+    const size_t nbx = 2 * (size_t)out_w, nby = 2 * (size_t)out_h;
+    const size_t nkx = (size_t)out_w * ksize_x, nky = (size_t)out_h * ksize_y;
+    const size_t tmp_floats = (size_t)channels * H * out_w;
+    const size_t k_off = ((nbx + nby) * sizeof(int) + 7) & ~(size_t)7;
+    const size_t t_off = (k_off + (nkx + nky) * sizeof(double) + 255) & ~(size_t)255;
+    STX_TRY(e->upload.ensure(t_off + tmp_floats * sizeof(float)));
+    char *base = static_cast<char *>(e->upload.ptr);
+    int *d_bx = reinterpret_cast<int *>(base), *d_by = d_bx + nbx;
+    double *d_kx = reinterpret_cast<double *>(base + k_off), *d_ky = d_kx + nkx;
+    float *tmp = reinterpret_cast<float *>(base + t_off);
+    STX_HIP(hipMemcpyAsync(d_bx, bounds_x, nbx * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    STX_HIP(hipMemcpyAsync(d_by, bounds_y, nby * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    STX_HIP(hipMemcpyAsync(d_kx, weights_x, nkx * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    STX_HIP(hipMemcpyAsync(d_ky, weights_y, nky * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    // Pillow runs the horizontal pass first, then the vertical pass on its float32 result
+    STX_TRY(resample_launch(e->stream, 0, src, channels, H, W, tmp, H, out_w, d_bx, d_kx, ksize_x, 0));
+    STX_TRY(resample_launch(e->stream, 1, tmp, channels, H, out_w, dst, out_h, out_w, d_by, d_ky,
+                            ksize_y, clamp_min_zero));
+    // the coefficient tables are host memory of the caller: finish the copies before returning
+    STX_HIP(hipStreamSynchronize(e->stream));
+    return STX_OK;
 }
 
 int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,

@@ -156,6 +156,50 @@ int roll_add_launch(hipStream_t s, float *acc, const float *src, int C, int h, i
     return STX_OK;
 }
 
+// ------------------------------------------------------------------------------- resampling ---
+// One separable pass of Pillow's 'F'-mode resampler (num_utils.resize, num_utils.py:90-108):
+// out[c][y][xx] = float( sum_x double(in[c][y][xmin + x]) * k[xx][x] ) along the last axis
+// (AXIS 0) or the row axis (AXIS 1); the windows and normalised weights come from the host.
+template <int AXIS>
+__global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ src, int C, int H,
+                                                       int W, float *__restrict__ dst, int OH,
+                                                       int OW, const int *__restrict__ bounds,
+                                                       const double *__restrict__ k, int ksize,
+                                                       int clamp) {
+    const size_t total = (size_t)C * OH * OW;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = i % OW;
+        const int oy = (i / OW) % OH;
+        const int c = i / ((size_t)OW * OH);
+        const int o = AXIS == 0 ? ox : oy;
+        const int first = bounds[2 * o], n = bounds[2 * o + 1];
+        const double *kk = k + (size_t)o * ksize;
+        double acc = 0.0;
+        if (AXIS == 0) {
+            const float *row = src + ((size_t)c * H + oy) * W + first;
+            for (int t = 0; t < n; ++t) acc += (double)row[t] * kk[t];
+        } else {
+            const float *col = src + ((size_t)c * H + first) * W + ox;
+            for (int t = 0; t < n; ++t) acc += (double)col[(size_t)t * W] * kk[t];
+        }
+        float v = (float)acc;
+        if (clamp) v = fmaxf(v, 0.f);
+        dst[i] = v;
+    }
+}
+
+int resample_launch(hipStream_t s, int axis, const float *src, int C, int H, int W, float *dst,
+                    int OH, int OW, const int *bounds, const double *k, int ksize, int clamp) {
+    const size_t total = (size_t)C * OH * OW;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+    if (axis == 0)
+        resample_kernel<0><<<blocks, 256, 0, s>>>(src, C, H, W, dst, OH, OW, bounds, k, ksize, clamp);
+    else
+        resample_kernel<1><<<blocks, 256, 0, s>>>(src, C, H, W, dst, OH, OW, bounds, k, ksize, clamp);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
 // --------------------------------------------------------------------------- regularizers ---
 struct RegArgs {
     const float *img;

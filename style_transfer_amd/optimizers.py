@@ -12,6 +12,7 @@ import numpy as np
 from PIL import Image
 
 from . import image_ops
+from .resample import BILINEAR, LANCZOS, resample_device
 
 
 def resize_chw(arr, hw, method=Image.LANCZOS):
@@ -72,13 +73,11 @@ class AdamOptimizer:
         old = [self.params, self.avg]
         self.params = last_iterate
         hw = self.params.shape[-2:]
-        for ew, method, clamp in ((self.g1, Image.LANCZOS, False), (self.g2, Image.BILINEAR, True),
-                                  (self.p1, Image.LANCZOS, False)):
-            host = resize_chw(ew.value.get(), hw, method)
-            if clamp:
-                host = np.maximum(0, host)
+        for ew, method, clamp in ((self.g1, LANCZOS, False), (self.g2, BILINEAR, True),
+                                  (self.p1, LANCZOS, False)):
+            resized = resample_device(self.engine, ew.value, hw, method, clamp_min_zero=clamp)
             ew.value.free()
-            ew.value = self.engine.to_device(host)
+            ew.value = resized
         self.avg = self.engine.empty(self.params.shape)
         for a in old:
             if a is not self.params:

@@ -21,7 +21,8 @@ from PIL import Image
 
 from . import image_ops
 from .config_system import ffloat
-from .optimizers import AdamOptimizer, LBFGSOptimizer, resize_chw
+from .optimizers import AdamOptimizer, LBFGSOptimizer
+from .resample import resample_device
 
 
 def resize_to_fit(image, size, scale_up=False, div=1):
@@ -257,8 +258,8 @@ class StyleTransfer:
                     self.aux_image.free()
                 self.aux_image = self.engine.to_device(self.pil_to_image(aux_scaled))
             if output_raw is not None:      # not the first scale: upsample the averaged iterate
-                resized = resize_chw(output_raw.get(), (h, w))
-                self.img = self.engine.to_device(np.ascontiguousarray(resized))
+                # model.resize_image (style_transfer.py:399-401): Lanczos, on the GPU
+                self.img = resample_device(self.engine, output_raw, (h, w))
                 self.optimizer.set_params(self.img)
             else:
                 biased_g1 = True

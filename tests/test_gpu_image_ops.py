@@ -133,3 +133,21 @@ def test_step_stats_and_uint8():
     u8 = image_ops.to_u8(eng, d_avg, MEAN)
     ref = np.uint8(np.clip((avg + MEAN)[::-1].transpose(1, 2, 0), 0, 255))
     assert np.array_equal(u8, ref)
+
+
+@pytest.mark.parametrize('hw,method', [((52, 75), 'lanczos'), ((26, 40), 'lanczos'),
+                                       ((52, 75), 'bilinear'), ((37, 80), 'lanczos')])
+def test_resample_is_bit_identical_to_pillow(hw, method):
+    """num_utils.resize (num_utils.py:90-108) = PIL 'F'-mode resize per channel."""
+    from PIL import Image
+    from style_transfer_amd.resample import resample_device
+    eng = gpu_engine()
+    rng = np.random.RandomState(0)
+    a = rng.uniform(-100, 100, (3, 37, 53)).astype(np.float32)
+    pil_method = Image.LANCZOS if method == 'lanczos' else Image.BILINEAR
+    ref = np.stack([np.asarray(Image.fromarray(a[c]).resize((hw[1], hw[0]), pil_method))
+                    for c in range(3)])
+    got = resample_device(eng, eng.to_device(a), hw, method).get()
+    assert np.array_equal(got, ref)
+    clamped = resample_device(eng, eng.to_device(a), hw, method, clamp_min_zero=True).get()
+    assert np.array_equal(clamped, np.maximum(0, ref))

@@ -117,3 +117,15 @@ def test_product_never_imports_the_oracle():
             if name.endswith('.py'):
                 text = open(os.path.join(dirpath, name)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text, name
+
+
+@pytest.mark.parametrize('hw,method', [((52, 75), 'lanczos'), ((26, 40), 'lanczos'),
+                                       ((52, 75), 'bilinear'), ((19, 53), 'bilinear')])
+def test_resample_coefficients_reproduce_pillow(hw, method):
+    from style_transfer_amd import resample
+    rng = np.random.RandomState(0)
+    a = rng.uniform(-100, 100, (3, 37, 53)).astype(np.float32)
+    pil_method = Image.LANCZOS if method == 'lanczos' else Image.BILINEAR
+    ref = np.stack([np.asarray(Image.fromarray(a[c]).resize((hw[1], hw[0]), pil_method))
+                    for c in range(3)])
+    assert np.array_equal(resample.resample_host(a, hw, method), ref)
