@@ -27,7 +27,8 @@ SOURCES = {
     'image_ops.hip': ['-ffp-contract=off'],
     'engine.cpp': [],
 }
-COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC,
+EXTRA = os.environ.get('STX_HIPCC_EXTRA', '').split()
+COMMON = EXTRA + ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC,
           '-Wall', '-Wno-unused-function']
 
 

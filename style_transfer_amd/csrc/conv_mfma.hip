@@ -211,9 +211,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
 
     constexpr int S_STORE = ((NS * 5 / 8) / 2) * 2;   // k-step before which the idle stage is filled
     int cur = 0;
+#ifndef STX_ABLATE
+#define STX_ABLATE 0   // timing experiments only: 1 no staging in the loop, 2 also no barriers,
+#endif                 // 3 also no LDS operand reads.  Results are wrong when non-zero.
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const bool more = chunk + 1 < c_end;
-        if (more) load_stage(chunk + 1);
+        if (more && STX_ABLATE == 0) load_stage(chunk + 1);
         if (DB) {
             wlc = wl + cur * STAGE;
             xlc = Xl + cur * STAGE;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
                 store_stage(cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (s + R - 1 < NS) {
+            if (s + R - 1 < NS && (STX_ABLATE < 3 || chunk == c_begin)) {
                 load_a(s + R - 1, av[(s + R - 1) % R]);
                 load_b(s + R - 1, bv[(s + R - 1) % R]);
             }
@@ -243,10 +246,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
             multiply(av[s % R], bv[s % R]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (STX_ABLATE < 2) __syncthreads();
         if (DB) {
             cur ^= 1;
-        } else if (more) {
+        } else if (more && STX_ABLATE == 0) {
             store_stage(0);
             __syncthreads();
         }

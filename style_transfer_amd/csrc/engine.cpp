@@ -611,6 +611,20 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
         }
         for (size_t bi = 0; bi < e->blobs.size(); ++bi) e->blobs[bi].scale = 224 / h224[bi];
     }
+    // let this GPU read and write the other GPUs of the node directly (tile and target copies of a
+    // multi-GPU farm go over xGMI); harmless when there is one GPU or access is already enabled
+    {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) == hipSuccess) {
+            for (int peer = 0; peer < n_dev; ++peer) {
+                int can = 0;
+                if (peer == device || hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can)
+                    continue;
+                (void)hipDeviceEnablePeerAccess(peer, 0);
+            }
+            (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is expected
+        }
+    }
     STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // The loss terms can run on a second stream beside the backward convolutions
     // (STX_SIDE_STREAM=1).  Measured on MI355X this is 1.7 % SLOWER (13.24 vs 13.02 ms per 1024^2

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libstx.so')
+LIB_PATH = os.environ.get('STX_LIB') or os.path.join(_HERE, 'csrc', 'libstx.so')
 
 HOST, DEVICE = 0, 1
 LAYER_INPUT, LAYER_CONV, LAYER_RELU, LAYER_POOL = 0, 1, 2, 3

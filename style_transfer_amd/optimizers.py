@@ -9,19 +9,9 @@ product and therefore commutes with the circular shift the reference applies to 
 """
 
 import numpy as np
-from PIL import Image
 
 from . import image_ops
 from .resample import BILINEAR, LANCZOS, resample_device
-
-
-def resize_chw(arr, hw, method=Image.LANCZOS):
-    """num_utils.resize (num_utils.py:90-108): per-channel PIL resampling in 'F' mode."""
-    arr = np.float32(arr)
-    out = np.zeros((arr.shape[0], hw[0], hw[1]), np.float32)
-    for c in range(arr.shape[0]):
-        out[c] = Image.fromarray(arr[c]).resize((hw[1], hw[0]), method)
-    return out
 
 
 class _Ewma:
