@@ -297,6 +297,30 @@ def main():
     out['e2e/final_raw'] = transfer.current_raw.copy()
     out['e2e/final_u8'] = np.asarray(transfer.current_output)
 
+    # ----------------- 4b. L-BFGS, VGG-16 with AVE pooling, two style images (configs 4 and 5)
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's1.png', 's2.png', '--size', '80',
+                '--min-size', '50', '--tile-size', '40', '--iterations', '3', '2', '-o', 'lbfgs',
+                '--model', 'vgg16_avgpool.prototxt', '--display', 'none', '--seed', '9']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    model_args2 = (os.path.join(REF, 'vgg16_avgpool.prototxt'), 'synthetic', mean, st.VGG16_SHAPES)
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args2, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args2, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(50, 64, 80)
+    styles_u8 = [smooth_image(51, 60, 48), smooth_image(52, 40, 72)]
+    log = []
+    np.random.seed(st.ARGS.seed)
+    transfer.transfer_multiscale([Image.fromarray(content_u8)],
+                                 [Image.fromarray(s) for s in styles_u8], None, None, callback=Cb())
+    out['e2e_lbfgs/content_u8'] = content_u8
+    out['e2e_lbfgs/style0_u8'], out['e2e_lbfgs/style1_u8'] = styles_u8
+    out['e2e_lbfgs/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e_lbfgs/log'] = np.float64(log)
+    out['e2e_lbfgs/final_raw'] = transfer.current_raw.copy()
+
     # ------------------------------------------------------------------ 5. parse_args defaults
     sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png']
     args = config_system.parse_args(st.STATE)
