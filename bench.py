@@ -121,12 +121,17 @@ def main():
         sys.exit('--gpus must be one of %s' % sorted(GRIDS))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an AMD GPU (no CPU path exists)')
+    # STX_BENCH_DEBUG_ONE_GPU=1 (debugging the N > 1 protocol on a 1-GPU box only): every rank
+    # uses GPU 0 and tiles travel over gloo through host memory.  Never a benchmark number.
+    debug_one_gpu = os.environ.get('STX_BENCH_DEBUG_ONE_GPU') == '1'
+    if debug_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('gloo' if debug_one_gpu else 'nccl', rank=rank, world_size=world)
 
     from style_transfer_amd import image_ops
     from style_transfer_amd.engine import DeviceArray, TileEngine
@@ -260,7 +265,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if debug_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 

@@ -38,6 +38,10 @@ class DistributedTiles:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._recv = {}
+        # gloo moves host memory only: GPU tensors are staged through the CPU (debug / CI path;
+        # on the GPU box the backend is nccl = RCCL and tensors travel device to device)
+        self.host_staged = self.device.type == 'cuda' and dist.get_backend(group) == 'gloo'
+        self.wire = torch.device('cpu') if self.host_staged else self.device
 
     def _sync(self):
         if self.device.type == 'cuda':
@@ -46,8 +50,16 @@ class DistributedTiles:
     def _buffer(self, key, shape, dtype=torch.float32):
         buf = self._recv.get(key)
         if buf is None or tuple(buf.shape) != tuple(shape):
-            buf = self._recv[key] = torch.empty(shape, dtype=dtype, device=self.device)
+            buf = self._recv[key] = torch.empty(shape, dtype=dtype, device=self.wire)
         return buf
+
+    def _out(self, tensor):
+        """A tensor as it goes on the wire."""
+        return tensor.contiguous().to(self.wire) if self.host_staged else tensor.contiguous()
+
+    def _in(self, tensor):
+        """A received tensor as the callbacks want it (on the compute device)."""
+        return tensor.to(self.device) if self.host_staged else tensor
 
     @staticmethod
     def _run(ops):
@@ -58,7 +70,7 @@ class DistributedTiles:
     def eval_sc_grad(self, rects, roll):
         """rects: the tile grid [(y0,y1,x0,x1)] (identical on all ranks); roll: (x, y) pixel
         shift, significant on rank 0.  Returns the summed loss on rank 0 (None elsewhere)."""
-        header = torch.zeros(2, dtype=torch.int64, device=self.device)
+        header = torch.zeros(2, dtype=torch.int64, device=self.wire)
         if self.rank == 0:
             header[0], header[1] = int(roll[0]), int(roll[1])
         dist.broadcast(header, 0, group=self.group)
@@ -76,13 +88,15 @@ class DistributedTiles:
                 if owner[t] == 0:
                     tiles[t] = tile
                 else:
-                    ops.append(dist.P2POp(dist.isend, tile.contiguous(), owner[t], self.group))
+                    ops.append(dist.P2POp(dist.isend, self._out(tile), owner[t], self.group))
             self._sync()
         else:
             for t in mine:
                 tiles[t] = self._buffer(('tile', t), shape(t))
                 ops.append(dist.P2POp(dist.irecv, tiles[t], 0, self.group))
         self._run(ops)
+        if self.rank != 0:
+            tiles = {t: self._in(buf) for t, buf in tiles.items()}
         self._sync()
 
         # ---- evaluate the local tiles (possibly concurrently, that is the callee's business)
@@ -112,15 +126,15 @@ class DistributedTiles:
                 self.put(rects[t], grad, roll)
                 total += loss
             for t, gbuf in incoming:
-                self.put(rects[t], gbuf, roll)
+                self.put(rects[t], self._in(gbuf), roll)
             for lbuf in loss_bufs.values():
                 total += float(lbuf.sum())
             return total
         if mine:
             for (loss, grad) in results:
-                ops.append(dist.P2POp(dist.isend, grad.contiguous(), 0, self.group))
+                ops.append(dist.P2POp(dist.isend, self._out(grad), 0, self.group))
             losses = torch.tensor([loss for loss, _ in results], dtype=torch.float64,
-                                  device=self.device)
+                                  device=self.wire)
             ops.append(dist.P2POp(dist.isend, losses, 0, self.group))
             self._run(ops)
             self._sync()
@@ -130,6 +144,8 @@ class DistributedTiles:
 def broadcast_targets(contents, styles, device, group=None):
     """Broadcasts rank 0's targets (lists of {layer: ndarray}) to every rank."""
     rank = dist.get_rank(group)
+    if torch.device(device).type == 'cuda' and dist.get_backend(group) == 'gloo':
+        device = 'cpu'                      # host-staged debug path, see DistributedTiles
     meta = [None]
     if rank == 0:
         meta[0] = ([{k: tuple(v.shape) for k, v in c.items()} for c in contents],
