@@ -161,8 +161,7 @@ int content_sums_launch(hipStream_t s, const float *feat, const float *content,
                         const ContentWindow &win, float *sums /*[2]*/);
 // diff (=|+=) coef / (abs_sum/n + EPS) * term, term = S (style) or F - Fc (content).
 int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
-                        const float *abs_sum, const float *partials, int n_partials, float coef,
-                        bool accumulate);
+                        const float *abs_sum, float coef, bool accumulate);
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef, bool accumulate);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);

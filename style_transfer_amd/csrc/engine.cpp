@@ -128,7 +128,7 @@ struct stx_engine {
     int n_contents = 0, n_styles = 0;
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
-    DevBuf gram_partials, gram, dsym, symm_partials, upload, img_scratch;
+    DevBuf gram_partials, gram, dsym, symm_partials, upload;
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
     size_t scalars_cap = 0, scalars_used = 0;
@@ -673,7 +673,7 @@ void stx_engine_destroy(stx_engine *e) {
     for (auto &c : e->contents) c.feat->release();
     for (auto &s : e->styles) s.gram->release();
     DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
-                      &e->upload, &e->img_scratch, &e->scalars, &e->dscalars, &e->red_scratch};
+                      &e->upload, &e->scalars, &e->dscalars, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
     if (e->scalars_host) (void)hipHostFree(e->scalars_host);
     if (e->dscalars_host) (void)hipHostFree(e->dscalars_host);
@@ -1066,8 +1066,8 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         ProfScope scope(e, "inject " + b.name, 0.0);
         for (const Term &t : terms[k]) {       // content terms come first, like the reference
             if (t.style)
-                STX_TRY(inject_style_launch(e->stream, b.diff.f(), t.src, b.count(), t.sums, nullptr,
-                                            0, t.coef, diff_written));
+                STX_TRY(inject_style_launch(e->stream, b.diff.f(), t.src, b.count(), t.sums, t.coef,
+                                            diff_written));
             else
                 STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), t.src, t.win,
                                               t.sums, t.coef, diff_written));

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void inject_style_kernel(float *__restrict__ d
 }
 
 int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
-                        const float *abs_sum, const float *, int, float coef, bool accumulate) {
+                        const float *abs_sum, float coef, bool accumulate) {
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
     if (accumulate)
         inject_style_kernel<true><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef);
