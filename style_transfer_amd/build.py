@@ -20,6 +20,7 @@ ARCH = 'gfx950'
 
 SOURCES = {
     'conv_mfma.hip': [],
+    'conv_wino.hip': [],
     'gram.hip': [],
     'pool.hip': [],
     'reduce.hip': [],

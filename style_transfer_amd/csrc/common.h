@@ -119,6 +119,15 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
 int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
 size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
 
+int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit);
+
+// 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
+ConvConfig wino_config_by_id(int id);
+size_t wino_packed_floats(const ConvConfig &cfg, int K, int M);
+int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                      const ConvConfig &cfg, float *packed);
+int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);
 int conv_small_pack(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,

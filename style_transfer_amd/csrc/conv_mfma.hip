@@ -58,6 +58,12 @@ struct ConvKernelArgs {
 // DB: two LDS stages.  The next chunk is written into the idle stage in the middle of the current
 // chunk's MFMAs (its global loads were issued a chunk earlier), so a chunk costs one barrier
 // instead of two and no wave ever sits in a write phase with the matrix pipe idle.
+// Block-uniform values that come out of an integer division are computed on the vector ALU (the
+// scalar unit has no divider) and stay in VGPRs; a buffer load whose scalar offset derives from
+// them is then wrapped in a waterfall loop per load.  Pinning them to SGPRs keeps the whole
+// address arithmetic of a chunk on the scalar unit.
+static __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 template <int KS, int KC, int TM, int TN, int WM, int WN, int PR, int PC, int EPI, bool PACKED,
           bool DB = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelArgs a) {
@@ -96,14 +102,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q = nb >> 3, r8 = nb & 7;
     const int L = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-    const int kslice = EPI == kEpiPartial ? L % a.ksplit : 0;
-    const int Lt = EPI == kEpiPartial ? L / a.ksplit : L;
-    const int ptile = Lt / m_tiles;
+    const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
+    const int Lt = sgpr(EPI == kEpiPartial ? L / a.ksplit : L);
+    const int ptile = sgpr(Lt / m_tiles);
     const int mtile = Lt - ptile * m_tiles;
-    const int c_begin = EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0;
-    const int c_end = EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks;
-    const int y0 = (ptile / a.tiles_x) * PR;
-    const int x0 = (ptile % a.tiles_x) * PC;
+    const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
+    const int c_end = sgpr(EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks);
+    const int y0 = sgpr((ptile / a.tiles_x) * PR);
+    const int x0 = sgpr((ptile % a.tiles_x) * PC);
     const int m0 = mtile * BM;
     const int HW = a.H * a.W;
 
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_mfma_kernel(ConvKernelAr
     u32x4 wreg[NW];
     unsigned xreg[NX];
     auto load_stage = [&](int chunk) {
-        const unsigned ws = w_base + (unsigned)chunk * w_chunk;
-        const unsigned xs = (unsigned)chunk * x_chunk;
+        const unsigned ws = (unsigned)sgpr((int)(w_base + (unsigned)chunk * w_chunk));
+        const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
 #pragma unroll
         for (int n = 0; n < NW; ++n) wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[n], ws, 0);
 #pragma unroll
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
 
 int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     if (!packed || p.ksize != 3 || (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad)) return 1;
-    if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;
+    if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;   // (ids >= 100: Winograd, allowed)
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
     const int n_chunks = ceil_div(p.K, cfg.kc);
     // All workgroups of a launch become resident at once while they fit (about five per CU for
@@ -612,7 +618,11 @@ int conv_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, bool
     set_error("conv_launch: no kernel for config %d epilogue %d packed %d", cfg.id, p.epilogue,
               (int)packed);
     return STX_ERR_UNSUPPORTED;
-reduce : {
+reduce:
+    return splitk_reduce_launch(s, p, ksplit);
+}
+
+int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
     SplitReduceArgs r;
     r.part = p.splitk_ws;
     r.y = p.y;
@@ -629,7 +639,6 @@ reduce : {
     splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, s>>>(r);
     STX_CHECK_LAUNCH();
     return STX_OK;
-}
 }
 
 }  // namespace stx
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Wl[W_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int y0 = (blockIdx.x / a.tiles_x) * PR, x0 = (blockIdx.x % a.tiles_x) * PC;
+    const int y0 = sgpr((blockIdx.x / a.tiles_x) * PR), x0 = sgpr((blockIdx.x % a.tiles_x) * PC);
     const int HW = a.H * a.W;
     constexpr unsigned kOob = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     u32x4 wreg;
     auto load_stage = [&](int chunk) {
         wreg = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (unsigned)chunk * (W_FLOATS * 4u), 0);
-        const unsigned xs = (unsigned)chunk * (unsigned)(KC * HW) * 4u;
+        const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * (unsigned)(KC * HW) * 4u));
 #pragma unroll
         for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
     };

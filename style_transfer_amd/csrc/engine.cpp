@@ -82,7 +82,7 @@ struct ConvParams {
     int cin = 0, cout = 0, ks = 0;
     DevBuf w, b;                              // Caffe layout on the device
     bool set = false;
-    std::map<int, std::unique_ptr<DevBuf>> packed;  // key = dir * 64 + config id
+    std::map<int, std::unique_ptr<DevBuf>> packed;  // key = dir * 1024 + config id
 };
 
 struct ContentTarget {
@@ -138,6 +138,7 @@ struct stx_engine {
     DevBuf red_scratch;                // float partials for image-op reductions
     std::vector<PendingLoss> pending;
 
+    bool winograd = true;   // 1-D Winograd F(2,3) for the 3x3 layers (STX_WINOGRAD=0: direct only)
     bool autotune = true;   // tile-config autotuning (process-wide cache, see choose_conv_config)
 
     // optional per-kernel-group timing (stx_profile_enable): event pairs around launch groups
@@ -280,13 +281,19 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
     }
-    const int key = dir * 64 + cfg.id;
+    const int key = dir * 1024 + cfg.id;
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
         const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
         std::unique_ptr<DevBuf> buf(new DevBuf);
-        STX_TRY(buf->ensure(conv_packed_floats(cfg, K, M, cp.ks) * sizeof(float)));
-        STX_TRY(conv_pack_weights(e->stream, cp.w.f(), cp.cout, cp.cin, cp.ks, dir, cfg, buf->f()));
+        if (cfg.id >= 100) {   // Winograd-transformed bank
+            STX_TRY(buf->ensure(wino_packed_floats(cfg, K, M) * sizeof(float)));
+            STX_TRY(wino_pack_weights(e->stream, cp.w.f(), cp.cout, cp.cin, dir, cfg, buf->f()));
+        } else {
+            STX_TRY(buf->ensure(conv_packed_floats(cfg, K, M, cp.ks) * sizeof(float)));
+            STX_TRY(conv_pack_weights(e->stream, cp.w.f(), cp.cout, cp.cin, cp.ks, dir, cfg,
+                                      buf->f()));
+        }
         it = cp.packed.emplace(key, std::move(buf)).first;
     }
     *out = it->second->f();
@@ -304,6 +311,14 @@ static std::mutex g_tuned_mutex;
 static std::map<std::vector<int>, int> g_tuned;
 
 int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out) {
+    // 3x3 layers with enough channels run the 1-D Winograd kernel (one third fewer MFMAs).  The
+    // choice depends on the shape only, never on timing: its rounding differs from the direct
+    // kernel's, and a given shape must always take the same path.
+    if (e->winograd && p.ksize == 3 && p.K >= 8 && p.M > 4) {
+        const char *force = getenv("STX_WINO_FORCE");   // tuning aid
+        *out = wino_config_by_id(force ? atoi(force) : (p.M >= 64 ? 0 : 1));
+        return STX_OK;
+    }
     const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
     *out = fallback;
     if (!e->autotune || p.ksize != 3 || p.K <= 4 || p.M <= 32) return STX_OK;
@@ -360,6 +375,11 @@ int attach_splitk(stx_engine *e, const ConvConfig &cfg, ConvProblem &p) {
     return STX_OK;
 }
 
+int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
+    if (cfg.id >= 100) return wino_launch(e->stream, cfg, p, conv_splitk_factor(cfg, p, true));
+    return conv_launch(e->stream, cfg, p, true);
+}
+
 int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     const Layer &L = e->layers[li];
     const Blob &b = e->blobs[L.bottom_blob];
@@ -383,7 +403,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
-    return conv_launch(e->stream, cfg, p, true);
+    return launch_conv(e, cfg, p);
 }
 
 int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused) {
@@ -405,19 +425,19 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
         // backward into a <= 4-channel blob (the image): dedicated 4x4x1-MFMA kernel
         if (fused) *fused = false;
         ConvParams &cpm = e->conv[li];
-        auto it = cpm.packed.find(1 * 64 + 63);
+        auto it = cpm.packed.find(1 * 1024 + 999);
         if (it == cpm.packed.end()) {
             std::unique_ptr<DevBuf> buf(new DevBuf);
             STX_TRY(buf->ensure(conv_small_packed_floats(cp.cout) * sizeof(float)));
             STX_TRY(conv_small_pack(e->stream, cp.w.f(), cp.cout, cp.cin, 1, buf->f()));
-            it = cpm.packed.emplace(1 * 64 + 63, std::move(buf)).first;
+            it = cpm.packed.emplace(1 * 1024 + 999, std::move(buf)).first;
         }
         ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
         return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
     }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 1, p, &cfg));   // tuned without the injection terms
-    const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;  // those two have no injecting epilogue
+    const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
     const float *packed = nullptr;
@@ -425,7 +445,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
     ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
-    return conv_launch(e->stream, cfg, p, true);
+    return launch_conv(e, cfg, p);
 }
 
 // Runs the layers needed for `needed` blobs, in graph order.  `relu_blob` (or -1) is rectified
@@ -640,6 +660,7 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     STX_HIP(hipEventCreate(&e->ev_tune0));
     STX_HIP(hipEventCreate(&e->ev_tune1));
     if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
+    if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
     e->scalars_cap = kScalarFloats;
     STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
@@ -1327,17 +1348,28 @@ int stx_image_to_u8(stx_engine *e, const float *img, int H, int W, const float m
 static int scratch_pack(stx_engine *e, const float *w, int Mo, int Ko, int ks, int dir,
                         const ConvConfig &cfg, const float **packed) {
     const int M = dir ? Ko : Mo, K = dir ? Mo : Ko;
-    STX_TRY(e->upload.ensure(conv_packed_floats(cfg, K, M, ks) * sizeof(float)));
-    STX_TRY(conv_pack_weights(e->stream, w, Mo, Ko, ks, dir, cfg, e->upload.f()));
+    if (cfg.id >= 100) {
+        STX_TRY(e->upload.ensure(wino_packed_floats(cfg, K, M) * sizeof(float)));
+        STX_TRY(wino_pack_weights(e->stream, w, Mo, Ko, dir, cfg, e->upload.f()));
+    } else {
+        STX_TRY(e->upload.ensure(conv_packed_floats(cfg, K, M, ks) * sizeof(float)));
+        STX_TRY(conv_pack_weights(e->stream, w, Mo, Ko, ks, dir, cfg, e->upload.f()));
+    }
     *packed = e->upload.f();
     return STX_OK;
+}
+
+// Same shape-only selection as the tile path (Winograd where it applies), without the tuner.
+static ConvConfig hook_config(stx_engine *e, int ksize, int K, int M, int H, int W) {
+    if (e->winograd && ksize == 3 && K >= 8 && M > 4) return wino_config_by_id(M >= 64 ? 0 : 1);
+    return conv_pick_config(ksize, K, M, H, W);
 }
 
 int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, const float *w,
                         const float *b, int Cout, int ksize, int relu, float *y) {
     if (!e || !x || !w || !y) return STX_ERR_ARG;
     STX_TRY(e->set_device());
-    const ConvConfig cfg = conv_pick_config(ksize, Cin, Cout, H, W);
+    const ConvConfig cfg = hook_config(e, ksize, Cin, Cout, H, W);
     const float *packed = nullptr;
     STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 0, cfg, &packed));
     ConvProblem p{};
@@ -1353,7 +1385,7 @@ int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, co
     p.relu = relu;
     p.epilogue = kEpiForward;
     STX_TRY(attach_splitk(e, cfg, p));
-    return conv_launch(e->stream, cfg, p, true);
+    return launch_conv(e, cfg, p);
 }
 
 int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, int W, const float *w,
@@ -1365,7 +1397,7 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
         STX_TRY(conv_small_pack(e->stream, w, Cout, Cin, 1, e->upload.f()));
         return conv_small_launch(e->stream, dy, e->upload.f(), dx, relu_mask_data, Cout, Cin, H, W);
     }
-    const ConvConfig cfg = conv_pick_config(ksize, Cout, Cin, H, W);
+    const ConvConfig cfg = hook_config(e, ksize, Cout, Cin, H, W);
     const float *packed = nullptr;
     STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 1, cfg, &packed));
     ConvProblem p{};
@@ -1380,7 +1412,7 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
     p.ksize = ksize;
     p.epilogue = kEpiDgrad;
     STX_TRY(attach_splitk(e, cfg, p));
-    return conv_launch(e->stream, cfg, p, true);
+    return launch_conv(e, cfg, p);
 }
 
 int stx_op_pool_forward(stx_engine *e, const float *x, int C, int H, int W, int mode, float *y) {
