@@ -21,6 +21,7 @@ ARCH = 'gfx950'
 SOURCES = {
     'conv_mfma.hip': [],
     'conv_wino.hip': [],
+    'conv_wino2.hip': [],
     'gram.hip': [],
     'pool.hip': [],
     'reduce.hip': [],

@@ -121,12 +121,36 @@ size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool pack
 
 int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit);
 
+// Kernel arguments shared by the Winograd kernels.
+struct WinoArgs {
+    const float *x;
+    const float *w;        // transformed filter bank in the kernel's own tile layout
+    float *y;
+    const float *bias;
+    const float *mask;
+    int K, M, H, W;
+    int n_chunks, tiles_x, tiles_y, m_tiles, ksplit;
+    int w_tile_stride;     // floats between consecutive output-channel tiles
+    int x_bytes, w_bytes;
+    int relu;
+    ConvInject inj;
+};
+
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
+// wino_config_by_id(0..2) are its variants, wino_config_by_id(100) is the 2-D kernel below; the
+// other three functions dispatch on cfg.id.
 ConvConfig wino_config_by_id(int id);
 size_t wino_packed_floats(const ConvConfig &cfg, int K, int M);
 int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
                       const ConvConfig &cfg, float *packed);
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+
+// 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
+ConvConfig wino2_config();
+size_t wino2_packed_floats(int K, int M);
+int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                       float *packed);
+int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);

@@ -28,19 +28,6 @@ namespace stx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-struct WinoArgs {
-    const float *x;
-    const float *w;        // packed [m_tile][(ci*3 + ky)*4 + i][BM]
-    float *y;
-    const float *bias;
-    const float *mask;
-    int K, M, H, W;
-    int n_chunks, tiles_x, tiles_y, m_tiles, ksplit;
-    int w_tile_stride;     // floats between consecutive output-channel tiles
-    int x_bytes, w_bytes;
-    int relu;
-    ConvInject inj;
-};
 
 // Wave grid WM x WN, each wave owns TM x TN blocks of 32 channels x 64 pixels (32 x-tiles).
 // Pixel patch: PR rows x 64*SEGS columns; PR * SEGS == TN * WN.
@@ -334,6 +321,7 @@ static const WinoVariant kWino[] = {
 };
 
 ConvConfig wino_config_by_id(int id) {
+    if (id >= 100) return wino2_config();
     const WinoVariant &v = kWino[id];
     ConvConfig c;
     c.id = 100 + id;                  // ids >= 100 mark Winograd configurations
@@ -348,6 +336,7 @@ ConvConfig wino_config_by_id(int id) {
 }
 
 size_t wino_packed_floats(const ConvConfig &cfg, int K, int M) {
+    if (cfg.id >= 200) return wino2_packed_floats(K, M);
     const size_t kpad = (size_t)ceil_div(K, cfg.kc) * cfg.kc;
     return (size_t)ceil_div(M, cfg.bm) * kpad * 12 * cfg.bm;
 }
@@ -385,6 +374,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Mo, int Ko, in
 
 int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
                       const ConvConfig &cfg, float *packed) {
+    if (cfg.id >= 200) return wino2_pack_weights(s, w_caffe, Mo, Ko, transpose_flip, packed);
     const int M = transpose_flip ? Ko : Mo;
     const int K = transpose_flip ? Mo : Ko;
     const int kpad = ceil_div(K, cfg.kc) * cfg.kc;
@@ -422,6 +412,7 @@ STX_WINO_VARIANT(2, 4, 2, 1, 1, 4, 4, 1)
 
 // Launches a Winograd configuration (cfg.id >= 100); `w` must come from wino_pack_weights.
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    if (cfg.id >= 200) return wino2_launch(s, cfg, p, ksplit);
     WinoArgs a;
     a.x = p.x;
     a.w = p.w;

@@ -1,0 +1,435 @@
+// 3x3 convolution through 2-D Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// Same job and interface as conv_mfma_kernel / conv_wino_kernel (forward + bias + ReLU,
+// backward-to-data + ReLU mask + loss-gradient terms, split-K partials) with 16 multiplies per
+// 2x2 output tile and input channel instead of 36 (Lavin & Gray):
+//     V = Bt d B   (d = 4x4 input patch at rows 2ty-1.., columns 2tx-1..)
+//     U = G g Gt   (g = 3x3 filter)                      -- formed once, when the bank is packed
+//     M[xi][nu] = sum over input channels of U[xi][nu] * V[xi][nu]
+//     out = At M A (2x2)
+//     Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//     At = [1 1 1 0; 0 1 -1 -1]
+// The sixteen (xi, nu) components are sixteen independent GEMMs D[m][t] = sum_k A[m][k] B[k][t]
+// with m = output channel, t = tile, k = input channel.
+//
+// Work split.  A workgroup of eight waves computes 64 channels x (4 rows x 64 columns) = 64 tiles.
+// Wave (xi, trow) owns transform row xi for the 32 tiles of tile row trow and both 32-channel
+// blocks: 2 x 4 (nu) accumulators of one v_mfma_f32_32x32x2_f32 block each, 128 registers, the
+// same budget as the other kernels.  The A and B operands of the four nu components sit next to
+// each other in LDS, so one ds_read_b128 feeds four MFMAs.  After the reduction the waves turn
+// their nu components into two output columns in registers, exchange those through LDS, and
+// each wave combines the four xi rows of a quarter of the channels into the two output rows.
+//
+// Staging.  Per chunk of 8 input channels: the transformed filter bank comes as a ready LDS
+// image (32 KB, four b128 loads per thread); the input patch is transformed on its way in, one
+// (channel, tile) per thread: sixteen loads -> Bt d B in registers -> four b128 LDS writes.  The
+// chunk is double buffered in LDS (2 x 64 KB), one barrier per chunk; the workgroup has the CU to
+// itself.
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace stx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 8, BM = 64, NT = 512, PR = 4, PC = 64;
+constexpr int U_FLOATS = 4 * KC * BM * 4;     // [xi][ci][m][nu]
+constexpr int V_FLOATS = 4 * KC * 64 * 4;     // [xi][ci][tile][nu]
+constexpr int STAGE = U_FLOATS + V_FLOATS;    // 64 KB
+constexpr size_t kLdsBytes = 2 * STAGE * sizeof(float);
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// The shared tail of every output pair: (m, yy, xx0) and (m, yy, xx0 + 1).
+template <int EPI>
+__device__ __forceinline__ void finish_pair(const WinoArgs &a, bool vec2, int HW, int kslice, int m,
+                                            int yy, int xx0, float2 v, float s_scale,
+                                            float c_scale) {
+    if (yy >= a.H || m >= a.M) return;
+    if (vec2) {
+        if (xx0 >= a.W) return;
+        const long idx = (long)m * HW + yy * a.W + xx0;
+        if (EPI == kEpiPartial) {
+            *reinterpret_cast<float2 *>(a.y + (long)kslice * a.M * HW + idx) = v;
+            return;
+        }
+        if (EPI == kEpiForward) {
+            if (a.bias) v.x += a.bias[m], v.y += a.bias[m];
+            if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+        } else {
+            if (a.mask) {
+                const float2 k = *reinterpret_cast<const float2 *>(a.mask + idx);
+                v.x = k.x > 0.f ? v.x : 0.f;
+                v.y = k.y > 0.f ? v.y : 0.f;
+            }
+            if (EPI == kEpiDgradInject) {
+                if (a.inj.content) {
+                    const float2 f = *reinterpret_cast<const float2 *>(a.inj.feat + idx);
+                    v.x += c_scale * (f.x - a.inj.content[content_index(a.inj.win, m, yy, xx0)]);
+                    v.y += c_scale * (f.y - a.inj.content[content_index(a.inj.win, m, yy, xx0 + 1)]);
+                }
+                if (a.inj.sgrad) {
+                    const float2 g = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx);
+                    v.x += s_scale * g.x;
+                    v.y += s_scale * g.y;
+                }
+            }
+        }
+        *reinterpret_cast<float2 *>(a.y + idx) = v;
+        return;
+    }
+    const float out[2] = {v.x, v.y};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int xx = xx0 + e;
+        if (xx >= a.W) continue;
+        const long idx = (long)m * HW + yy * a.W + xx;
+        float o = out[e];
+        if (EPI == kEpiPartial) {
+            a.y[(long)kslice * a.M * HW + idx] = o;
+            continue;
+        }
+        if (EPI == kEpiForward) {
+            if (a.bias) o += a.bias[m];
+            if (a.relu) o = fmaxf(o, 0.f);
+        } else {
+            if (a.mask) o = a.mask[idx] > 0.f ? o : 0.f;
+            if (EPI == kEpiDgradInject) {
+                if (a.inj.content)
+                    o += c_scale *
+                         (a.inj.feat[idx] - a.inj.content[content_index(a.inj.win, m, yy, xx)]);
+                if (a.inj.sgrad) o += s_scale * a.inj.sgrad[idx];
+            }
+        }
+        a.y[idx] = o;
+    }
+}
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = sgpr(tid >> 6);
+    const int xi = wave & 3, trow = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // XCD-aware work order, see conv_mfma.hip
+    const int m_tiles = a.m_tiles;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
+    const int Lt = sgpr(EPI == kEpiPartial ? L / a.ksplit : L);
+    const int ptile = sgpr(Lt / m_tiles);
+    const int mtile = Lt - ptile * m_tiles;
+    const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
+    const int c_end = sgpr(EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks);
+    const int y0 = sgpr((ptile / a.tiles_x) * PR);
+    const int x0 = sgpr((ptile % a.tiles_x) * PC);
+    const int m0 = mtile * BM;
+    const int HW = a.H * a.W;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // ---- staging roles: this thread transforms the patch of channel `wave` of the chunk for
+    // tile `lane` (tile row lane / 32, tile column lane % 32).  Channels past K fall beyond the
+    // descriptor's range and read as zero, like everything outside the plane.
+    unsigned xvoff[4][4];
+    {
+        const int ty = lane >> 5, tx = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = y0 + 2 * ty - 1 + i;
+            const bool row_ok = (unsigned)yy < (unsigned)a.H;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = x0 + 2 * tx - 1 + j;
+                xvoff[i][j] = row_ok && (unsigned)xx < (unsigned)a.W
+                                  ? (unsigned)(wave * HW + yy * a.W + xx) * 4u : kOob;
+            }
+        }
+    }
+    const unsigned w_base = (unsigned)(mtile * a.w_tile_stride) * 4u;
+    constexpr unsigned w_chunk = (unsigned)U_FLOATS * 4u;
+    const unsigned x_chunk = (unsigned)(KC * HW) * 4u;
+
+    u32x4 wreg[4];
+    float xreg[4][4];
+    auto load_stage = [&](int chunk) {
+        const unsigned ws = (unsigned)sgpr((int)(w_base + (unsigned)chunk * w_chunk));
+        const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + n * NT) * 16u, ws, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xreg[i][j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[i][j], xs, 0));
+    };
+    auto store_stage = [&](int buf) {
+        float *ul = lds + buf * STAGE;
+        float *vl = ul + U_FLOATS;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) reinterpret_cast<u32x4 *>(ul)[tid + n * NT] = wreg[n];
+        // The asm keeps the loaded values opaque until here: otherwise the compiler forms the
+        // differences right behind the loads, inside the MFMA loop, with a vmcnt wait there.
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[i][j] = xreg[i][j];
+                asm volatile("" : "+v"(d[i][j]));
+            }
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j];
+            t[1][j] = d[1][j] + d[2][j];
+            t[2][j] = d[2][j] - d[1][j];
+            t[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            f32x4 v;
+            v[0] = t[x][0] - t[x][2];
+            v[1] = t[x][1] + t[x][2];
+            v[2] = t[x][2] - t[x][1];
+            v[3] = t[x][1] - t[x][3];
+            *reinterpret_cast<f32x4 *>(vl + ((x * KC + wave) * 64 + lane) * 4) = v;
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+    // operand addresses of k-step q (channels 2q and 2q+1; lane half h supplies channel 2q + h)
+    const int a_off = ((xi * KC + half) * BM + l31) * 4;
+    const int b_off = U_FLOATS + ((xi * KC + half) * 64 + trow * 32 + l31) * 4;
+    constexpr int NS = KC / 2;
+
+    load_stage(c_begin);
+    store_stage(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const bool more = chunk + 1 < c_end;
+        if (more) load_stage(chunk + 1);
+        const float *base = lds + cur * STAGE;
+        f32x4 av[2][2], bv[2];
+        av[0][0] = *reinterpret_cast<const f32x4 *>(base + a_off);
+        av[0][1] = *reinterpret_cast<const f32x4 *>(base + a_off + 32 * 4);
+        bv[0] = *reinterpret_cast<const f32x4 *>(base + b_off);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) {
+                const int o = (2 * (s + 1)) * 64 * 4;       // BM == 64 tiles: same stride
+                av[(s + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(base + a_off + o);
+                av[(s + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(base + a_off + o + 32 * 4);
+                bv[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(base + b_off + o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i][c], bv[s & 1][c],
+                                                                      acc[i][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
+    float2 *ex = reinterpret_cast<float2 *>(lds);     // [wave][i*16 + r][lane], 128 KB in all
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float c0 = acc[i][0][r], c1 = acc[i][1][r], c2 = acc[i][2][r], c3 = acc[i][3][r];
+            ex[(wave * 32 + i * 16 + r) * 64 + lane] = make_float2(c0 + c1 + c2, c1 - c2 - c3);
+        }
+    __syncthreads();
+
+    float s_scale = 0.f, c_scale = 0.f;
+    if (EPI == kEpiDgradInject) {
+        const float n = (float)((size_t)a.M * HW);
+        if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
+        if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
+    }
+    const bool vec2 = ((a.W & 1) | (((size_t)a.y | (size_t)a.mask | (size_t)a.inj.feat |
+                                     (size_t)a.inj.sgrad) & 7)) == 0;
+    const int yy = y0 + 2 * trow, xx0 = x0 + 2 * l31;
+    // this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel blocks: D register
+    // r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * xi + rr;
+            float2 p[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) p[x] = ex[((trow * 4 + x) * 32 + i * 16 + r) * 64 + lane];
+            const int m = m0 + i * 32 + rr + 8 * xi + 4 * half;
+            finish_pair<EPI>(a, vec2, HW, kslice, m, yy, xx0,
+                             make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
+                             s_scale, c_scale);
+            finish_pair<EPI>(a, vec2, HW, kslice, m, yy + 1, xx0,
+                             make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y),
+                             s_scale, c_scale);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+ConvConfig wino2_config() {
+    ConvConfig c;
+    c.id = 200;                       // ids >= 200 mark the 2-D Winograd configuration
+    c.bm = BM;
+    c.kc = KC;
+    c.pr = PR;
+    c.pc = PC;
+    c.threads = NT;
+    c.lds_bytes = kLdsBytes;
+    return c;
+}
+
+size_t wino2_packed_floats(int K, int M) {
+    return (size_t)ceil_div(M, BM) * ceil_div(K, KC) * U_FLOATS;
+}
+
+// packed[mt][chunk][xi][ci][mm][nu] = (G g Gt)[xi][nu] of the filter W(m = mt*64 + mm, k = chunk*8 + ci)
+__global__ void wino2_pack_kernel(const float *__restrict__ w, int Mo, int Ko, int transpose_flip,
+                                  int M, int K, int n_chunks, float *__restrict__ packed,
+                                  size_t total) {
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int nu = idx % 4;
+        const int mm = (idx / 4) % BM;
+        const int ci = (idx / (4 * BM)) % KC;
+        const int x = (idx / (4 * BM * KC)) % 4;
+        const int chunk = (idx / U_FLOATS) % n_chunks;
+        const int mt = idx / ((size_t)U_FLOATS * n_chunks);
+        const int m = mt * BM + mm, k = chunk * KC + ci;
+        float v = 0.f;
+        if (m < M && k < K) {
+            // rows of G: [1 0 0], [.5 .5 .5], [.5 -.5 .5], [0 0 1]
+            float row[3];   // (G g)[x][b]
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float g[3];
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa) {
+                    const int t = aa * 3 + b;
+                    g[aa] = transpose_flip ? w[((size_t)k * Ko + m) * 9 + (8 - t)]
+                                           : w[((size_t)m * Ko + k) * 9 + t];
+                }
+                row[b] = x == 0 ? g[0]
+                       : x == 1 ? (g[0] + g[1] + g[2]) * 0.5f
+                       : x == 2 ? (g[0] - g[1] + g[2]) * 0.5f
+                                : g[2];
+            }
+            v = nu == 0 ? row[0]
+              : nu == 1 ? (row[0] + row[1] + row[2]) * 0.5f
+              : nu == 2 ? (row[0] - row[1] + row[2]) * 0.5f
+                        : row[2];
+        }
+        packed[idx] = v;
+    }
+}
+
+int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                       float *packed) {
+    const int M = transpose_flip ? Ko : Mo;
+    const int K = transpose_flip ? Mo : Ko;
+    const size_t total = wino2_packed_floats(K, M);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    wino2_pack_kernel<<<blocks, 256, 0, s>>>(w_caffe, Mo, Ko, transpose_flip, M, K,
+                                             ceil_div(K, KC), packed, total);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+template <int EPI>
+static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
+    auto kern = conv_wino2_kernel<EPI>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(lds=%zu): %s", kLdsBytes, hipGetErrorString(e));
+        return STX_ERR_HIP;
+    }
+    kern<<<n_wg, NT, kLdsBytes, s>>>(args);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    WinoArgs a;
+    a.x = p.x;
+    a.w = p.w;
+    a.y = p.y;
+    a.bias = p.bias;
+    a.mask = p.mask;
+    a.K = p.K;
+    a.M = p.M;
+    a.H = p.H;
+    a.W = p.W;
+    a.n_chunks = ceil_div(p.K, KC);
+    a.tiles_x = ceil_div(p.W, PC);
+    a.tiles_y = ceil_div(p.H, PR);
+    a.m_tiles = ceil_div(p.M, BM);
+    a.ksplit = 1;
+    a.w_tile_stride = a.n_chunks * U_FLOATS;
+    a.relu = p.relu;
+    a.inj = p.inject;
+    const double xb = 4.0 * p.K * (double)p.H * p.W;
+    const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);
+    if (xb >= 2147483648.0 || wb >= 2147483648.0) {
+        set_error("wino2_launch: plane set exceeds the 2 GiB buffer-addressing limit");
+        return STX_ERR_UNSUPPORTED;
+    }
+    a.x_bytes = (int)xb;
+    a.w_bytes = (int)wb;
+    const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
+    int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
+    const bool split = ksplit > 1 && p.splitk_ws &&
+                       p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
+    if (split) {
+        a.ksplit = ksplit;
+        a.y = p.splitk_ws;
+        n_wg *= ksplit;
+        STX_TRY(wino2_launch_epi<kEpiPartial>(s, a, n_wg));
+        return splitk_reduce_launch(s, p, ksplit);
+    }
+    if (p.epilogue == kEpiForward) return wino2_launch_epi<kEpiForward>(s, a, n_wg);
+    if (inject) return wino2_launch_epi<kEpiDgradInject>(s, a, n_wg);
+    if (p.epilogue == kEpiDgrad) return wino2_launch_epi<kEpiDgrad>(s, a, n_wg);
+    set_error("wino2_launch: no kernel for epilogue %d", p.epilogue);
+    return STX_ERR_UNSUPPORTED;
+}
+
+}  // namespace stx

@@ -310,15 +310,19 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
 static std::mutex g_tuned_mutex;
 static std::map<std::vector<int>, int> g_tuned;
 
+// 3x3 layers with enough channels run a Winograd kernel (one third / five ninths fewer MFMAs).
+// The choice depends on the shape only, never on timing: the rounding differs between the
+// kernels, and a given shape must always take the same path.
+static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out) {
+    (void)H, (void)W;
+    if (!e->winograd || ksize != 3 || K < 8 || M <= 4) return false;
+    const char *force = getenv("STX_WINO_FORCE");   // tuning aid: 0..2 1-D variants, 100 2-D
+    *out = wino_config_by_id(force ? atoi(force) : (M >= 64 ? 0 : 1));
+    return true;
+}
+
 int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out) {
-    // 3x3 layers with enough channels run the 1-D Winograd kernel (one third fewer MFMAs).  The
-    // choice depends on the shape only, never on timing: its rounding differs from the direct
-    // kernel's, and a given shape must always take the same path.
-    if (e->winograd && p.ksize == 3 && p.K >= 8 && p.M > 4) {
-        const char *force = getenv("STX_WINO_FORCE");   // tuning aid
-        *out = wino_config_by_id(force ? atoi(force) : (p.M >= 64 ? 0 : 1));
-        return STX_OK;
-    }
+    if (wino_choice(e, p.ksize, p.K, p.M, p.H, p.W, out)) return STX_OK;
     const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
     *out = fallback;
     if (!e->autotune || p.ksize != 3 || p.K <= 4 || p.M <= 32) return STX_OK;
@@ -1361,7 +1365,8 @@ static int scratch_pack(stx_engine *e, const float *w, int Mo, int Ko, int ks, i
 
 // Same shape-only selection as the tile path (Winograd where it applies), without the tuner.
 static ConvConfig hook_config(stx_engine *e, int ksize, int K, int M, int H, int W) {
-    if (e->winograd && ksize == 3 && K >= 8 && M > 4) return wino_config_by_id(M >= 64 ? 0 : 1);
+    ConvConfig cfg;
+    if (wino_choice(e, ksize, K, M, H, W, &cfg)) return cfg;
     return conv_pick_config(ksize, K, M, H, W);
 }
 
