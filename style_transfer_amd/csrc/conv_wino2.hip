@@ -31,6 +31,12 @@
 
 #include "common.h"
 
+#ifdef STX_ABLATE
+#define STX_ABLATE_V STX_ABLATE
+#else
+#define STX_ABLATE_V 0
+#endif
+
 namespace stx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -146,29 +152,31 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
 
     // ---- staging roles: this thread transforms the patch of channel `wave` of the chunk for
-    // tile `lane` (tile row lane / 32, tile column lane % 32).  Channels past K fall beyond the
-    // descriptor's range and read as zero, like everything outside the plane.
-    unsigned xvoff[4][4];
+    // tile `lane` (tile row lane / 32, tile column lane % 32).  The four columns of a patch row
+    // are one 16-byte load (dword aligned; neighbouring lanes overlap by half, which the texture
+    // unit coalesces).  Rows outside the plane get an offset beyond the descriptor's range and
+    // read as zero, so do channels past K; columns outside the plane are patched when the
+    // values are consumed (only workgroups on the left / right edge pay for that).
+    const int st_x = x0 + 2 * (lane & 31) - 1;            // first patch column
+    const bool left = st_x < 0;                           // x = -1: load columns 0..3, shift later
+    unsigned xvoff[4];
     {
-        const int ty = lane >> 5, tx = lane & 31;
+        const int ty = lane >> 5;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = y0 + 2 * ty - 1 + i;
-            const bool row_ok = (unsigned)yy < (unsigned)a.H;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int xx = x0 + 2 * tx - 1 + j;
-                xvoff[i][j] = row_ok && (unsigned)xx < (unsigned)a.W
-                                  ? (unsigned)(wave * HW + yy * a.W + xx) * 4u : kOob;
-            }
+            const int xx = left ? 0 : st_x;
+            xvoff[i] = (unsigned)yy < (unsigned)a.H && xx < a.W
+                           ? (unsigned)(wave * HW + yy * a.W + xx) * 4u : kOob;
         }
     }
+    const bool edge_l = x0 == 0, edge_r = x0 + PC + 2 > a.W;      // workgroup-uniform
     const unsigned w_base = (unsigned)(mtile * a.w_tile_stride) * 4u;
     constexpr unsigned w_chunk = (unsigned)U_FLOATS * 4u;
     const unsigned x_chunk = (unsigned)(KC * HW) * 4u;
 
     u32x4 wreg[4];
-    float xreg[4][4];
+    f32x4 xreg[4];
     auto load_stage = [&](int chunk) {
         const unsigned ws = (unsigned)sgpr((int)(w_base + (unsigned)chunk * w_chunk));
         const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
@@ -177,10 +185,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + n * NT) * 16u, ws, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                xreg[i][j] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[i][j], xs, 0));
+            xreg[i] = __builtin_bit_cast(f32x4,
+                                         __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[i], xs, 0));
     };
     auto store_stage = [&](int buf) {
         float *ul = lds + buf * STAGE;
@@ -197,6 +203,23 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                 d[i][j] = xreg[i][j];
                 asm volatile("" : "+v"(d[i][j]));
             }
+        if (edge_l) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i][3] = left ? d[i][2] : d[i][3];
+                d[i][2] = left ? d[i][1] : d[i][2];
+                d[i][1] = left ? d[i][0] : d[i][1];
+                d[i][0] = left ? 0.f : d[i][0];
+            }
+        }
+        if (edge_r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = st_x + j < a.W;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i][j] = ok ? d[i][j] : 0.f;
+            }
+        }
         float t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -229,14 +252,27 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int b_off = U_FLOATS + ((xi * KC + half) * 64 + trow * 32 + l31) * 4;
     constexpr int NS = KC / 2;
 
+    // Pipeline.  The loads of chunk c+2 are issued right after chunk c+1 went from registers to
+    // the idle LDS buffer, so they have a whole chunk of matrix work to land.  The two waves that
+    // share a SIMD (w and w + 4, i.e. the two tile rows) do that hand-over at different k-steps:
+    // while one of them runs its transform and LDS writes the other keeps the matrix pipe busy.
     load_stage(c_begin);
     store_stage(0);
+    if (c_begin + 1 < c_end) load_stage(c_begin + 1);
     __syncthreads();
 
+#ifndef STX_ABLATE
+#define STX_ABLATE 0   // timing experiments only (see conv_mfma.hip); results are wrong when non-zero
+#endif
     int cur = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const bool more = chunk + 1 < c_end;
-        if (more) load_stage(chunk + 1);
+        auto hand_over = [&]() {
+            if (more && (STX_ABLATE == 0 || STX_ABLATE >= 3)) {
+                if (STX_ABLATE != 3) store_stage(cur ^ 1);
+                if (chunk + 2 < c_end && STX_ABLATE != 4) load_stage(chunk + 2);
+            }
+        };
         const float *base = lds + cur * STAGE;
         f32x4 av[2][2], bv[2];
         av[0][0] = *reinterpret_cast<const f32x4 *>(base + a_off);
@@ -258,10 +294,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                     acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i][c], bv[s & 1][c],
                                                                       acc[i][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (s == 0 && trow == 0) hand_over();
+            if (s == 2 && trow != 0) hand_over();
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_stage(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (STX_ABLATE != 2 && STX_ABLATE != 8) __syncthreads();
+        if (STX_ABLATE == 0 || STX_ABLATE >= 3) cur ^= 1;
     }
 
     // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
