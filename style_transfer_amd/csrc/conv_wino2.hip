@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -41,6 +42,7 @@ namespace stx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -155,88 +157,126 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // tile `lane` (tile row lane / 32, tile column lane % 32).  The four columns of a patch row
     // are one 16-byte load (dword aligned; neighbouring lanes overlap by half, which the texture
     // unit coalesces).  Rows outside the plane get an offset beyond the descriptor's range and
-    // read as zero, so do channels past K; columns outside the plane are patched when the
-    // values are consumed (only workgroups on the left / right edge pay for that).
+    // read as zero, so do channels past K.  Columns outside the plane are zeroed when the values
+    // are consumed, by workgroups on the left / right edge only: x = -1 is the first patch column
+    // of tile column 0, x >= W can only be one of the last two patch columns of a tile that
+    // still has a column inside (tiles entirely outside compute garbage nobody stores).
+    // The one patch row whose x = -1 would lie before the start of the tensor (channel 0, row 0
+    // of the first workgroup) is loaded from x = 0 and shifted by one instead.
     const int st_x = x0 + 2 * (lane & 31) - 1;            // first patch column
-    const bool left = st_x < 0;                           // x = -1: load columns 0..3, shift later
+    const bool left = st_x < 0;
+    const bool corner = wave == 0 && y0 == 0 && x0 == 0;  // uniform: lane 0, patch row 1
     unsigned xvoff[4];
     {
         const int ty = lane >> 5;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = y0 + 2 * ty - 1 + i;
-            const int xx = left ? 0 : st_x;
-            xvoff[i] = (unsigned)yy < (unsigned)a.H && xx < a.W
-                           ? (unsigned)(wave * HW + yy * a.W + xx) * 4u : kOob;
+            const int off = wave * HW + yy * a.W + st_x;
+            xvoff[i] = (unsigned)yy < (unsigned)a.H && st_x < a.W
+                           ? (unsigned)(off < 0 ? 0 : off) * 4u : kOob;
         }
     }
     const bool edge_l = x0 == 0, edge_r = x0 + PC + 2 > a.W;      // workgroup-uniform
+    const bool ok2 = st_x + 2 < a.W, ok3 = st_x + 3 < a.W;
     const unsigned w_base = (unsigned)(mtile * a.w_tile_stride) * 4u;
     constexpr unsigned w_chunk = (unsigned)U_FLOATS * 4u;
     const unsigned x_chunk = (unsigned)(KC * HW) * 4u;
+    // LDS byte offsets of this thread's writes within a buffer
+    const unsigned u_dst = (unsigned)tid * 16u;
+    const unsigned v_dst = (unsigned)(U_FLOATS + (wave * 64 + lane) * 4) * 4u;
 
     u32x4 wreg[4];
     f32x4 xreg[4];
+    f32x2 tq[4][2];    // Bt d, two columns at a time
+    f32x4 vq[4];       // Bt d B, one transform row each
+
+    // The hand-over of a chunk from the staging registers to LDS, cut into single-instruction
+    // pieces.  While a wave's SIMD partner has an MFMA in flight (64 cycles) the wave can issue a
+    // handful of other instructions for free, but a wave that presents nothing but MFMAs leaves
+    // its partner one issue slot per MFMA: a contiguous block of ~40 staging instructions in one
+    // wave then takes longer than the partner's whole chunk of matrix work (measured,
+    // tools/ubench/coissue.hip).  So the pieces are dealt out one per MFMA.  Bt d B is sixteen
+    // packed adds (v_pk_add_f32 with operand-select / negate modifiers, which the compiler does
+    // not form by itself); the results stay in their own registers until they are written.
+#define STX_PK(dst, a_, b_, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(dst) : "v"(a_), "v"(b_))
+    auto u_load = [&](int n, unsigned ws) {
+        wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + n * NT) * 16u, ws, 0);
+    };
+    auto x_load = [&](int i, unsigned xs) {
+        xreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[i], xs, 0));
+    };
+    auto u_write = [&](int n, char *ldsb) {
+        *reinterpret_cast<u32x4 *>(ldsb + u_dst + n * (NT * 16)) = wreg[n];
+    };
+    auto fix_edges = [&]() {
+        // The asm keeps the loaded values opaque until here: otherwise the compiler forms the
+        // differences right behind the loads, with a vmcnt wait in the wrong place.
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xreg[i]));
+        if (corner) {
+            const bool c = lane == 0;
+            xreg[1].w = c ? xreg[1].z : xreg[1].w;
+            xreg[1].z = c ? xreg[1].y : xreg[1].z;
+            xreg[1].y = c ? xreg[1].x : xreg[1].y;
+        }
+        if (edge_l) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xreg[i].x = left ? 0.f : xreg[i].x;
+        }
+        if (edge_r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xreg[i].z = ok2 ? xreg[i].z : 0.f;
+                xreg[i].w = ok3 ? xreg[i].w : 0.f;
+            }
+        }
+    };
+    // rows: t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3 on column pair h
+    auto row_op = [&](int q) {
+        const int h = q >> 2, which = q & 3;
+        const f32x2 d0 = h ? xreg[0].zw : xreg[0].xy, d1 = h ? xreg[1].zw : xreg[1].xy;
+        const f32x2 d2 = h ? xreg[2].zw : xreg[2].xy, d3 = h ? xreg[3].zw : xreg[3].xy;
+        if (which == 0) STX_PK(tq[0][h], d0, d2, "neg_lo:[0,1] neg_hi:[0,1]");
+        if (which == 1) STX_PK(tq[1][h], d1, d2, "");
+        if (which == 2) STX_PK(tq[2][h], d2, d1, "neg_lo:[0,1] neg_hi:[0,1]");
+        if (which == 3) STX_PK(tq[3][h], d1, d3, "neg_lo:[0,1] neg_hi:[0,1]");
+    };
+    // columns, with P = (t[.][0], t[.][1]) and Q = (t[.][2], t[.][3]) of transform row x:
+    //   (v0, v1) = (P.x - Q.x, P.y + Q.x)      (v2, v3) = (Q.x - P.y, P.y - Q.y)
+    auto col_op = [&](int q) {
+        const int x = q >> 1;
+        f32x2 r;
+        if ((q & 1) == 0) {
+            STX_PK(r, tq[x][0], tq[x][1], "op_sel_hi:[1,0] neg_lo:[0,1]");
+            vq[x].xy = r;
+        } else {
+            STX_PK(r, tq[x][0], tq[x][1], "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]");
+            vq[x].zw = r;
+        }
+    };
+    auto v_write = [&](int x, char *ldsb) {
+        *reinterpret_cast<f32x4 *>(ldsb + v_dst + x * (KC * 64 * 16)) = vq[x];
+    };
     auto load_stage = [&](int chunk) {
         const unsigned ws = (unsigned)sgpr((int)(w_base + (unsigned)chunk * w_chunk));
         const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-            wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + n * NT) * 16u, ws, 0);
+        for (int n = 0; n < 4; ++n) u_load(n, ws);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            xreg[i] = __builtin_bit_cast(f32x4,
-                                         __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[i], xs, 0));
+        for (int i = 0; i < 4; ++i) x_load(i, xs);
     };
     auto store_stage = [&](int buf) {
-        float *ul = lds + buf * STAGE;
-        float *vl = ul + U_FLOATS;
+        char *ldsb = reinterpret_cast<char *>(lds) + buf * (STAGE * 4);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) reinterpret_cast<u32x4 *>(ul)[tid + n * NT] = wreg[n];
-        // The asm keeps the loaded values opaque until here: otherwise the compiler forms the
-        // differences right behind the loads, inside the MFMA loop, with a vmcnt wait there.
-        float d[4][4];
+        for (int n = 0; n < 4; ++n) u_write(n, ldsb);
+        fix_edges();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < 8; ++q) row_op(q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d[i][j] = xreg[i][j];
-                asm volatile("" : "+v"(d[i][j]));
-            }
-        if (edge_l) {
+        for (int q = 0; q < 8; ++q) col_op(q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[i][3] = left ? d[i][2] : d[i][3];
-                d[i][2] = left ? d[i][1] : d[i][2];
-                d[i][1] = left ? d[i][0] : d[i][1];
-                d[i][0] = left ? 0.f : d[i][0];
-            }
-        }
-        if (edge_r) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = st_x + j < a.W;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) d[i][j] = ok ? d[i][j] : 0.f;
-            }
-        }
-        float t[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = d[0][j] - d[2][j];
-            t[1][j] = d[1][j] + d[2][j];
-            t[2][j] = d[2][j] - d[1][j];
-            t[3][j] = d[1][j] - d[3][j];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            f32x4 v;
-            v[0] = t[x][0] - t[x][2];
-            v[1] = t[x][1] + t[x][2];
-            v[2] = t[x][2] - t[x][1];
-            v[3] = t[x][1] - t[x][3];
-            *reinterpret_cast<f32x4 *>(vl + ((x * KC + wave) * 64 + lane) * 4) = v;
-        }
+        for (int x = 0; x < 4; ++x) v_write(x, ldsb);
     };
 
     f32x16 acc[2][4];
@@ -252,55 +292,78 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int b_off = U_FLOATS + ((xi * KC + half) * 64 + trow * 32 + l31) * 4;
     constexpr int NS = KC / 2;
 
-    // Pipeline.  The loads of chunk c+2 are issued right after chunk c+1 went from registers to
-    // the idle LDS buffer, so they have a whole chunk of matrix work to land.  The two waves that
-    // share a SIMD (w and w + 4, i.e. the two tile rows) do that hand-over at different k-steps:
-    // while one of them runs its transform and LDS writes the other keeps the matrix pipe busy.
-    load_stage(c_begin);
-    store_stage(0);
-    if (c_begin + 1 < c_end) load_stage(c_begin + 1);
-    __syncthreads();
-
-#ifndef STX_ABLATE
-#define STX_ABLATE 0   // timing experiments only (see conv_mfma.hip); results are wrong when non-zero
-#endif
-    int cur = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const bool more = chunk + 1 < c_end;
-        auto hand_over = [&]() {
-            if (more && (STX_ABLATE == 0 || STX_ABLATE >= 3)) {
-                if (STX_ABLATE != 3) store_stage(cur ^ 1);
-                if (chunk + 2 < c_end && STX_ABLATE != 4) load_stage(chunk + 2);
-            }
-        };
+    // One chunk of matrix work out of LDS buffer `cur`, with (STORE) the hand-over of the next
+    // chunk into the other buffer and (LOAD) the loads of the chunk after that dealt out between
+    // the MFMAs: pieces 0-3 filter-bank writes, 4-7 filter-bank loads, 8-15 row adds, 16-19 patch
+    // loads, 20-27 column adds, 28-31 patch writes.  sched_barrier pins the order.
+    auto run_chunk = [&](int cur, int chunk, auto store_c, auto load_c) {
+        constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
         const float *base = lds + cur * STAGE;
+        char *ldsb = reinterpret_cast<char *>(lds) + (cur ^ 1) * (STAGE * 4);
+        unsigned ws = 0, xs = 0;
+        if (LOAD) {
+            ws = (unsigned)sgpr((int)(w_base + (unsigned)(chunk + 2) * w_chunk));
+            xs = (unsigned)sgpr((int)((unsigned)(chunk + 2) * x_chunk));
+        }
         f32x4 av[2][2], bv[2];
         av[0][0] = *reinterpret_cast<const f32x4 *>(base + a_off);
         av[0][1] = *reinterpret_cast<const f32x4 *>(base + a_off + 32 * 4);
         bv[0] = *reinterpret_cast<const f32x4 *>(base + b_off);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if (s + 1 < NS) {
-                const int o = (2 * (s + 1)) * 64 * 4;       // BM == 64 tiles: same stride
-                av[(s + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(base + a_off + o);
-                av[(s + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(base + a_off + o + 32 * 4);
-                bv[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(base + b_off + o);
-            }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) {
+                    const int m = c * 2 + i, p = s * 8 + m;
+                    __builtin_amdgcn_sched_barrier(0);
                     acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i][c], bv[s & 1][c],
                                                                       acc[i][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 0 && trow == 0) hand_over();
-            if (s == 2 && trow != 0) hand_over();
-            __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < NS && m < 3) {      // operands of the next k-step
+                        const int o = (2 * (s + 1)) * 64 * 4;       // BM == 64 tiles: same stride
+                        if (m == 0) av[(s + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(base + a_off + o);
+                        if (m == 1) av[(s + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(base + a_off + o + 32 * 4);
+                        if (m == 2) bv[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(base + b_off + o);
+                    }
+                    if (STORE) {
+                        if (p < 4) u_write(p, ldsb);
+                        if (p == 8) fix_edges();
+                        if (p >= 8 && p < 16) row_op(p - 8);
+                        if (p >= 20 && p < 28) col_op(p - 20);
+                        if (p >= 28) v_write(p - 28, ldsb);
+                    }
+                    if (LOAD) {
+                        if (p >= 4 && p < 8) u_load(p - 4, ws);
+                        if (p >= 16 && p < 20) x_load(p - 16, xs);
+                    }
+                }
         }
-        if (STX_ABLATE != 2 && STX_ABLATE != 8) __syncthreads();
-        if (STX_ABLATE == 0 || STX_ABLATE >= 3) cur ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    load_stage(c_begin);
+    store_stage(0);
+    if (c_begin + 1 < c_end) load_stage(c_begin + 1);
+    __syncthreads();
+
+    int cur = 0;
+    int chunk = c_begin;
+    for (; chunk + 2 < c_end; ++chunk) {
+        run_chunk(cur, chunk, yes{}, yes{});
+        __syncthreads();
+        cur ^= 1;
     }
+    if (chunk + 1 < c_end) {
+        run_chunk(cur, chunk, yes{}, no{});
+        __syncthreads();
+        cur ^= 1;
+        ++chunk;
+    }
+    run_chunk(cur, chunk, no{}, no{});
+    __syncthreads();
 
     // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
     float2 *ex = reinterpret_cast<float2 *>(lds);     // [wave][i*16 + r][lane], 128 KB in all

@@ -1,0 +1,75 @@
+// Standalone timing harness for conv_wino2.hip (tuning aid, not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I style_transfer_amd/csrc \
+//         [-DSTX_WINO2_TIMING] tools/ubench/wino2_bench.hip -o /tmp/wino2_bench
+// With STX_WINO2_TIMING the kernel accumulates, per wave of workgroup 0, the core-clock cycles
+// spent in its compute segments, hand-over segments and barrier waits; the harness prints them.
+#include "../../style_transfer_amd/csrc/conv_wino2.hip"
+
+#include <vector>
+
+namespace stx {
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+int splitk_reduce_launch(hipStream_t, const ConvProblem &, int) { return 0; }
+}  // namespace stx
+
+static void run(int K, int M, int H, int W, int epilogue) {
+    using namespace stx;
+    const size_t xn = (size_t)K * H * W, yn = (size_t)M * H * W, wn = wino2_packed_floats(K, M);
+    float *x, *y, *w, *mask;
+    hipMalloc(&x, xn * 4);
+    hipMalloc(&y, yn * 4);
+    hipMalloc(&mask, yn * 4);
+    hipMalloc(&w, wn * 4);
+    std::vector<float> h(std::max(xn, std::max(wn, yn)));
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 1023) / 1024.f - 0.5f;
+    hipMemcpy(x, h.data(), xn * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, h.data(), wn * 4, hipMemcpyHostToDevice);
+    hipMemcpy(mask, h.data(), yn * 4, hipMemcpyHostToDevice);
+    ConvProblem p{};
+    p.x = x, p.w = w, p.y = y, p.bias = nullptr, p.mask = epilogue == kEpiDgrad ? mask : nullptr;
+    p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = 1, p.epilogue = epilogue;
+    const ConvConfig cfg = wino2_config();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) wino2_launch(0, cfg, p, 1);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) wino2_launch(0, cfg, p, 1);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    const double flop = 2.0 * M * K * 9 * H * W;
+    printf("K %4d M %4d %4dx%-4d epi %d: %.3f ms  %.1f TFLOP/s (direct-equivalent)  %.1f%% of MFMA time\n",
+           K, M, H, W, epilogue, ms, flop / ms / 1e9, 100.0 * (flop * 16 / 36 / 157.3e12) / (ms * 1e-3));
+#ifdef STX_WINO2_TIMING
+    long long t[8][8];
+    hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
+    const int chunks = (K + 7) / 8;
+    long long pb[8][4];
+    hipMemcpyFromSymbol(pb, HIP_SYMBOL(stx::g_wino2_probe), sizeof(pb));
+    for (int wv = 0; wv < 8; ++wv)
+        printf("   wave %d: per chunk  compute %6.0f  hand-over %6.0f (wait %5.0f store %5.0f load %5.0f)  barrier %6.0f   total %7.0f cycles\n", wv,
+               (double)t[wv][0] / chunks, (double)t[wv][1] / chunks, (double)t[wv][4] / chunks,
+               (double)t[wv][5] / chunks, (double)t[wv][6] / chunks, (double)t[wv][2] / chunks,
+               (double)t[wv][3] / chunks);
+    for (int wv = 0; wv < 8; wv += 4)
+        printf("   wave %d store stage: U writes issued %5.0f  VALU %5.0f  V writes issued %5.0f\n", wv,
+               (double)pb[wv][0] / chunks, (double)pb[wv][1] / chunks, (double)pb[wv][2] / chunks);
+#endif
+    hipFree(x), hipFree(y), hipFree(w), hipFree(mask);
+}
+
+int main() {
+    run(512, 512, 128, 128, stx::kEpiForward);
+    run(64, 64, 1024, 1024, stx::kEpiForward);
+    run(512, 512, 128, 128, stx::kEpiDgrad);
+    return 0;
+}
