@@ -259,6 +259,12 @@ int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed);
  * valid after stx_sync. */
 int stx_last_tile_ms(stx_engine *e, float *ms);
 
+/* Matrix-core work of the convolutions of the same call: `algorithmic` counts every layer as a
+ * direct convolution (2 * Cout * Cin * k * k * H * W, the figure SURVEY.md section 8d uses),
+ * `issued` what the kernels actually put on the MFMA units (the Winograd kernels issue 2/3 or
+ * 4/9 of it).  Gram / SYMM products are not included. */
+int stx_last_tile_flops(stx_engine *e, double *algorithmic, double *issued);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,7 @@ struct stx_engine {
     std::vector<std::unique_ptr<DevBuf>> sgrad_tap;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
+    double flop_algorithmic = 0, flop_issued = 0;   // matrix work of the current / last tile call
     std::vector<Layer> layers;
     std::vector<Blob> blobs;
     std::map<std::string, int> blob_index, layer_index;
@@ -310,14 +311,22 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
 static std::mutex g_tuned_mutex;
 static std::map<std::vector<int>, int> g_tuned;
 
-// 3x3 layers with enough channels run a Winograd kernel (one third / five ninths fewer MFMAs).
-// The choice depends on the shape only, never on timing: the rounding differs between the
-// kernels, and a given shape must always take the same path.
+// 3x3 layers with enough channels run a Winograd kernel: 2-D F(2x2,3x3) (4/9 of the direct
+// kernel's MFMAs) when at least half a 64-channel tile is used, else 1-D F(2,3) (2/3).  The
+// choice depends on the shape only, never on timing: the rounding differs between the kernels,
+// and a given shape must always take the same path.  STX_CONV_ALGO=direct|wino1|wino2 (read at
+// every call) overrides it for tests and measurements.
 static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out) {
     (void)H, (void)W;
-    if (!e->winograd || ksize != 3 || K < 8 || M <= 4) return false;
-    const char *force = getenv("STX_WINO_FORCE");   // tuning aid: 0..2 1-D variants, 100 2-D
-    *out = wino_config_by_id(force ? atoi(force) : (M >= 64 ? 0 : 1));
+    if (ksize != 3 || K < 8 || M <= 4) return false;
+    const char *algo = getenv("STX_CONV_ALGO");
+    if (algo && *algo) {
+        if (!strcmp(algo, "direct")) return false;
+        if (!strcmp(algo, "wino2")) { *out = wino_config_by_id(100); return true; }
+        if (!strcmp(algo, "wino1")) { *out = wino_config_by_id(M >= 64 ? 0 : 1); return true; }
+    }
+    if (!e->winograd) return false;
+    *out = M > 32 ? wino_config_by_id(100) : wino_config_by_id(1);
     return true;
 }
 
@@ -380,6 +389,11 @@ int attach_splitk(stx_engine *e, const ConvConfig &cfg, ConvProblem &p) {
 }
 
 int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
+    // bookkeeping for stx_last_tile_flops: algorithmic = direct convolution, issued = what the
+    // chosen kernel puts on the matrix cores (tile padding not counted)
+    const double direct = 2.0 * p.M * p.K * p.ksize * p.ksize * (double)p.H * p.W;
+    e->flop_algorithmic += direct;
+    e->flop_issued += cfg.id >= 200 ? direct * 4.0 / 9.0 : cfg.id >= 100 ? direct * 2.0 / 3.0 : direct;
     if (cfg.id >= 100) return wino_launch(e->stream, cfg, p, conv_splitk_factor(cfg, p, true));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -437,6 +451,9 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
             it = cpm.packed.emplace(1 * 1024 + 999, std::move(buf)).first;
         }
         ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
+        const double direct = 2.0 * p.M * p.K * 9 * (double)p.H * p.W;
+        e->flop_algorithmic += direct;
+        e->flop_issued += direct * 4.0 / p.M;    // the 4x4x1 MFMA computes four output channels
         return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
     }
     ConvConfig cfg;
@@ -475,6 +492,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
 
 int begin_timing(stx_engine *e) {
     STX_HIP(hipEventRecord(e->ev_start, e->stream));
+    e->flop_algorithmic = e->flop_issued = 0;
     return STX_OK;
 }
 
@@ -1481,6 +1499,17 @@ int stx_last_tile_ms(stx_engine *e, float *ms) {
     STX_TRY(e->set_device());
     STX_HIP(hipEventSynchronize(e->ev_stop));
     STX_HIP(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return STX_OK;
+}
+
+int stx_last_tile_flops(stx_engine *e, double *algorithmic, double *issued) {
+    if (!e || !algorithmic || !issued) return STX_ERR_ARG;
+    if (!e->timed) {
+        set_error("stx_last_tile_flops: no tile has been evaluated");
+        return STX_ERR_STATE;
+    }
+    *algorithmic = e->flop_algorithmic;
+    *issued = e->flop_issued;
     return STX_OK;
 }
 

@@ -315,6 +315,12 @@ class TileEngine:
             rows.append((label, float(ms), float(flops)))
         return rows
 
+    def last_tile_flops(self):
+        """(algorithmic, issued) matrix-core FLOP of the convolutions of the last tile call."""
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        lib.call('stx_last_tile_flops', self.handle, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
     def last_tile_ms(self):
         ms = ctypes.c_float(0)
         lib.call('stx_last_tile_ms', self.handle, ctypes.byref(ms))

@@ -92,6 +92,7 @@ SIGNATURES = {
     'stx_op_pool_forward': [_vp, _vp, _i, _i, _i, _i, _vp],
     'stx_op_pool_backward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     'stx_last_tile_ms': [_vp, c_float_p],
+    'stx_last_tile_flops': [_vp, c_double_p, c_double_p],
     'stx_profile_enable': [_vp, _i],
     'stx_profile_read': [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_sz)],
 }

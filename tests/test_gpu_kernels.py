@@ -17,11 +17,19 @@ pytestmark = pytest.mark.gpu
 
 CONV_CASES = [  # (Cin, Cout, H, W): SURVEY section 8c list + shapes that hit every tile config
     (3, 64, 33, 47), (64, 64, 32, 32), (256, 512, 9, 11), (64, 128, 70, 65), (128, 256, 40, 40),
-    (512, 512, 16, 16), (64, 3, 37, 50), (128, 64, 24, 72), (20, 36, 19, 31)]
+    (512, 512, 16, 16), (64, 3, 37, 50), (128, 64, 24, 72), (20, 36, 19, 31), (16, 70, 13, 200),
+    (72, 40, 130, 129)]
+# every convolution kernel family on every shape it accepts; None = the engine's own choice
+CONV_ALGOS = [None, 'direct', 'wino1', 'wino2']
 
 
+@pytest.mark.parametrize('algo', CONV_ALGOS)
 @pytest.mark.parametrize('cin,cout,h,w', CONV_CASES)
-def test_conv_forward_and_backward_data(cin, cout, h, w):
+def test_conv_forward_and_backward_data(cin, cout, h, w, algo, monkeypatch):
+    if algo:
+        monkeypatch.setenv('STX_CONV_ALGO', algo)     # read by the library at every call
+    else:
+        monkeypatch.delenv('STX_CONV_ALGO', raising=False)
     eng = gpu_engine()
     rng = np.random.RandomState(cin * 7 + cout + h)
     x = rng.standard_normal((cin, h, w)).astype(np.float32)

@@ -52,17 +52,10 @@ static void run(int K, int M, int H, int W, int epilogue) {
 #ifdef STX_WINO2_TIMING
     long long t[8][8];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
-    const int chunks = (K + 7) / 8;
-    long long pb[8][4];
-    hipMemcpyFromSymbol(pb, HIP_SYMBOL(stx::g_wino2_probe), sizeof(pb));
-    for (int wv = 0; wv < 8; ++wv)
-        printf("   wave %d: per chunk  compute %6.0f  hand-over %6.0f (wait %5.0f store %5.0f load %5.0f)  barrier %6.0f   total %7.0f cycles\n", wv,
-               (double)t[wv][0] / chunks, (double)t[wv][1] / chunks, (double)t[wv][4] / chunks,
-               (double)t[wv][5] / chunks, (double)t[wv][6] / chunks, (double)t[wv][2] / chunks,
-               (double)t[wv][3] / chunks);
-    for (int wv = 0; wv < 8; wv += 4)
-        printf("   wave %d store stage: U writes issued %5.0f  VALU %5.0f  V writes issued %5.0f\n", wv,
-               (double)pb[wv][0] / chunks, (double)pb[wv][1] / chunks, (double)pb[wv][2] / chunks);
+    const int chunks = (K + 7) / 8 - 2;
+    for (int wv = 0; wv < 8; wv += 3)
+        printf("   wave %d: per chunk  work %6.0f  barrier %6.0f   total %7.0f cycles\n", wv,
+               (double)t[wv][0] / chunks, (double)t[wv][2] / chunks, (double)t[wv][3] / chunks);
 #endif
     hipFree(x), hipFree(y), hipFree(w), hipFree(mask);
 }
