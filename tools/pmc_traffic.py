@@ -23,7 +23,9 @@ def per_dispatch(path, counter):
     return rows
 
 
-def main(fetch_csv, write_csv, size=1024):
+def main(fetch_csv, write_csv, size=2048, tiles_per_step=4):
+    """size: edge of the (square) image the Adam kernel runs on; tiles_per_step: tile evaluations
+    between two Adam launches (bench.py at N = 1: 2048, 4)."""
     fetch = per_dispatch(fetch_csv, 'FETCH_SIZE')
     write = per_dispatch(write_csv, 'WRITE_SIZE')
     out = {}
@@ -37,7 +39,7 @@ def main(fetch_csv, write_csv, size=1024):
         factor = expected_adam / adam_bytes
         tile = [(k, v) for k, v in step if not re.search(
             r'adam_kernel|regularizers|tile_move|step_stats|finish_partials|copyBuffer|fillBuffer', k)]
-        raw = sum(v for _, v in tile) * 1024
+        raw = sum(v for _, v in tile) * 1024 / tiles_per_step
         out[name] = {'adam_measured_bytes': adam_bytes, 'adam_expected_bytes': expected_adam,
                      'correction': factor, 'tile_raw_bytes': raw, 'tile_bytes': raw * factor,
                      'kernels': len(tile)}
@@ -45,11 +47,11 @@ def main(fetch_csv, write_csv, size=1024):
         for k, v in tile:
             short = re.sub(r'\(.*', '', k)
             short = re.sub(r'^void ', '', short)
-            by[short[:70]] += v * 1024 * factor
+            by[short[:70]] += v * 1024 * factor / tiles_per_step
         out[name]['by_kernel_MB'] = {k: round(v / 1e6, 1) for k, v in by.most_common(8)}
     out['hbm_bytes_per_tile_iteration'] = out['fetch']['tile_bytes'] + out['write']['tile_bytes']
     print(json.dumps(out, indent=1))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *[int(a) for a in sys.argv[3:5]])
