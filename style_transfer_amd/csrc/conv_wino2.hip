@@ -38,6 +38,10 @@
 #define STX_ABLATE_V 0
 #endif
 
+#ifndef STX_W2_SKIP
+#define STX_W2_SKIP 0   // timing experiments (tools/ubench/wino2_bench.hip): 1 no filter loads, 2 no patch
+#endif                 // loads in the main loop.  Wrong results when non-zero.
+
 namespace stx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
     const int Lt = sgpr(EPI == kEpiPartial ? L / a.ksplit : L);
+    // (channel tile slowest, so that an XCD keeps one filter slice in L2, measured no different)
     const int ptile = sgpr(Lt / m_tiles);
     const int mtile = Lt - ptile * m_tiles;
     const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
@@ -333,8 +338,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                         if (p >= 20 && p < 28) col_op(p - 20);
                         if (p >= 28) v_write(p - 28, ldsb);
                     }
-                    if (LOAD) {
+                    if (LOAD && !(STX_W2_SKIP & 1)) {
                         if (p >= 4 && p < 8) u_load(p - 4, ws);
+                    }
+                    if (LOAD && !(STX_W2_SKIP & 2)) {
                         if (p >= 16 && p < 20) x_load(p - 16, xs);
                     }
                 }

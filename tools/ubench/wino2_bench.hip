@@ -62,6 +62,8 @@ static void run(int K, int M, int H, int W, int epilogue) {
 
 int main() {
     run(512, 512, 128, 128, stx::kEpiForward);
+    run(256, 256, 256, 256, stx::kEpiForward);
+    run(128, 128, 512, 512, stx::kEpiForward);
     run(64, 64, 1024, 1024, stx::kEpiForward);
     run(512, 512, 128, 128, stx::kEpiDgrad);
     return 0;
