@@ -44,6 +44,13 @@
 
 namespace stx {
 
+#ifdef STX_WINO2_TIMING   // cycle counters for tools/ubench/wino2_bench.hip
+__device__ long long g_wino2_timing[8][8];
+#define STX_T(var) const long long var = clock64()
+#else
+#define STX_T(var) const long long var = 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -356,13 +363,32 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     if (c_begin + 1 < c_end) load_stage(c_begin + 1);
     __syncthreads();
 
+    // Cycle counters (tools/ubench/wino2_bench.hip) put a chunk at ~4900 cycles against 4096 of
+    // pure matrix work: the SIMD arbitrates its pipe by age, the older wave of a pair runs at its
+    // own rate (64 cycles per MFMA + ~36 for its interleaved pieces: 3190 per chunk), the younger
+    // gets the gaps and runs its tail alone (4630).  s_setprio only swaps the roles; padding
+    // either or both waves with s_nop to one MFMA per 128 cycles, alternating priority per
+    // k-step, strict ping-pong with two barriers, and the barrier moved between k-steps 2 and 3
+    // were all measured and are no faster.
     int cur = 0;
     int chunk = c_begin;
+    long long t_work = 0, t_barrier = 0;
+    STX_T(t_begin);
     for (; chunk + 2 < c_end; ++chunk) {
+        STX_T(t0);
         run_chunk(cur, chunk, yes{}, yes{});
+        STX_T(t1);
         __syncthreads();
+        STX_T(t2);
+        t_work += t1 - t0, t_barrier += t2 - t1;
         cur ^= 1;
     }
+#ifdef STX_WINO2_TIMING
+    if (blockIdx.x == 0 && lane == 0) {
+        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = t_barrier;
+        g_wino2_timing[wave][3] = clock64() - t_begin;
+    }
+#endif
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
         __syncthreads();
