@@ -167,6 +167,7 @@ int pool_backward_launch(hipStream_t s, const float *dy, const float *x, int C, 
 // Gram: partial products over split-K slices, then a fixed-order reduction.
 struct GramPlan {
     int C, HW, splits, tiles;      // tiles = lower-triangular 64x64 tiles
+    int parts;                     // partial tiles written per slice (4: one per wave)
     size_t partial_floats;
 };
 GramPlan gram_plan(int C, int HW);

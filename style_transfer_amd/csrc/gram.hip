@@ -17,6 +17,7 @@
 // 32 lanes of an operand read walk the channel axis with an odd stride (conflict-free).
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -38,7 +39,8 @@ GramPlan gram_plan(int C, int HW) {
     splits = std::min(splits, ceil_div(HW, 8 * kGP));   // at least eight stages per slice
     splits = std::max(splits, 1);
     p.splits = splits;
-    p.partial_floats = (size_t)p.splits * p.tiles * kGT * kGT;
+    p.parts = 1;
+    p.partial_floats = (size_t)p.splits * p.parts * p.tiles * kGT * kGT;
     return p;
 }
 
@@ -54,6 +56,7 @@ __device__ __forceinline__ void tile_coords(int tile, int &ti, int &tj) {
 template <bool VEC4>
 __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__restrict__ F, int C,
                                                               int HW, int tiles, int slice,
+                                                              int parts,
                                                               float *__restrict__ partials) {
     __shared__ float At[kGT * kGLd];
     __shared__ float Bt[kGT * kGLd];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__res
             }
         }
     }
-    float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
+    float *out = partials + ((size_t)split * parts * tiles + tile) * (kGT * kGT);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -162,16 +165,165 @@ __global__ __launch_bounds__(256, 2) void gram_partial_kernel(const float *__res
     }
 }
 
+// Wide variant (h*w % 4 == 0, 16-byte aligned rows).  The 64-pixel stage is split over the four
+// waves instead of the 64x64 output: a wave reads its 16 pixels as two 16-byte groups per
+// channel row (lane half h takes pixels 8g + 4h .. +3; MFMA i of a group multiplies pixel 8g + i
+// from lanes 0-31 with pixel 8g + 4 + i from lanes 32-63) and owns all four 32x32 blocks, so one
+// ds_read_b128 per operand block feeds eight MFMAs (the narrow kernel needs two LDS reads per
+// MFMA).  On a diagonal tile A and B are the same rows and the upper block is skipped.  Rows are
+// padded to 68 floats: the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte slots.
+// The waves' partial tiles are added in wave order through LDS before the tile is written.
+constexpr int kGLdW = kGP + 4;
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void gram_partial_wide_kernel(const float *__restrict__ F, int C,
+                                                                   int HW, int tiles, int slice,
+                                                                   unsigned f_bytes,
+                                                                   float *__restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float At[kGT * kGLdW];
+    __shared__ __attribute__((aligned(16))) float Bt[kGT * kGLdW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    int ti, tj;
+    tile_coords(tile, ti, tj);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    const bool diag = ti == tj;
+    const int p_begin = split * slice;
+    const int p_end = min(HW, p_begin + slice);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: four float4 of the A tile (and of the B tile) per thread and stage through buffer
+    // loads; rows past C get an out-of-range offset (-> 0), a stage only changes the scalar offset
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, f_bytes, 0x00020000);
+    unsigned aoff[4], boff[4];
+    int ldst[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;                 // float4 index in the 64 x 16 tile
+        const int ch = e >> 4, px = (e & 15) * 4;
+        const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+        aoff[n] = ca < C ? (unsigned)(ca * HW + px) * 4u : kOob;
+        boff[n] = cb < C && !diag ? (unsigned)(cb * HW + px) * 4u : kOob;
+        ldst[n] = ch * kGLdW + px;
+    }
+    u32x4g ra[4], rb[4];
+    auto load = [&](int p0) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(p0 * 4);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ra[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, aoff[n], so, 0);
+        if (!diag) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rb[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, boff[n], so, 0);
+        }
+    };
+    auto store = [&](int p0) {
+        // the last stage of a slice may reach past p_end (a multiple of 4): those pixels belong
+        // to the next slice or the next channel row and must not count
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const bool ok = p0 + ((tid + 256 * n) & 15) * 4 < p_end;
+            u32x4g va = ra[n], vb = rb[n];
+            if (!ok) va = u32x4g{0, 0, 0, 0}, vb = u32x4g{0, 0, 0, 0};
+            *reinterpret_cast<u32x4g *>(At + ldst[n]) = va;
+            if (!diag) *reinterpret_cast<u32x4g *>(Bt + ldst[n]) = vb;
+        }
+    };
+
+    const float *ap = At + l31 * kGLdW + wave * 16 + half * 4;
+    const float *bp = (diag ? At : Bt) + l31 * kGLdW + wave * 16 + half * 4;
+
+    if (p_begin < p_end) {
+        load(p_begin);
+        store(p_begin);
+        __syncthreads();
+        for (int p0 = p_begin; p0 < p_end; p0 += kGP) {
+            const bool more = p0 + kGP < p_end;
+            if (more) load(p0 + kGP);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                f32x4g a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *reinterpret_cast<const f32x4g *>(ap + i * 32 * kGLdW + g * 8);
+                    b[i] = *reinterpret_cast<const f32x4g *>(bp + i * 32 * kGLdW + g * 8);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (diag && j > i) continue;      // upper block of a diagonal tile
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k],
+                                                                              acc[i][j], 0, 0, 0);
+                        }
+            }
+            __syncthreads();
+            if (more) {
+                store(p0 + kGP);
+                __syncthreads();
+            }
+        }
+    }
+    // add the four waves' partial tiles in wave order through LDS (deterministic), then one
+    // coalesced write of the 64x64 tile
+    __syncthreads();
+    float *red = At;                                   // 64 x 64 floats fit in the A stage
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float *q = red + row * kGT + j * 32 + l31;
+                        *q = w == 0 ? acc[i][j][r] : *q + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        reinterpret_cast<float4 *>(out)[tid + 256 * n] = reinterpret_cast<const float4 *>(red)[tid + 256 * n];
+}
+
 int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials) {
     int slice = ceil_div(plan.HW, plan.splits);
     slice = ceil_div(slice, kGP) * kGP;
-    const bool vec4 = plan.HW % 4 == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
-    if (vec4)
+    const bool aligned = (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
+    const double bytes = 4.0 * plan.C * (double)plan.HW;
+    if (plan.HW % 4 == 0 && aligned && bytes < 2147483648.0 && !getenv("STX_GRAM_NARROW")) {
+        gram_partial_wide_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
+            feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, partials);
+        STX_CHECK_LAUNCH();
+        return STX_OK;
+    }
+    // narrow kernel: one partial per slice, at stride `parts` (the other slots stay zero)
+    if (plan.parts > 1)
+        STX_HIP(hipMemsetAsync(partials, 0, plan.partial_floats * sizeof(float), s));
+    if (plan.HW % 4 == 0 && aligned)
         gram_partial_kernel<true><<<plan.tiles * plan.splits, 256, 0, s>>>(
-            feat, plan.C, plan.HW, plan.tiles, slice, partials);
+            feat, plan.C, plan.HW, plan.tiles, slice, plan.parts, partials);
     else
         gram_partial_kernel<false><<<plan.tiles * plan.splits, 256, 0, s>>>(
-            feat, plan.C, plan.HW, plan.tiles, slice, partials);
+            feat, plan.C, plan.HW, plan.tiles, slice, plan.parts, partials);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
@@ -263,7 +415,7 @@ int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &pla
     // block partial sums live behind the Gram partials (the caller sizes the buffer for both)
     float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
     const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
-    gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits, scale,
+    gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits * plan.parts, scale,
                                               gram_out, target, dsym, block_sumsq);
     STX_CHECK_LAUNCH();
     if (target) STX_TRY(sum_partials_launch(s, block_sumsq, blocks, sumsq));
