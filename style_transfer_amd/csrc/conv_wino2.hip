@@ -420,6 +420,92 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int yy = y0 + 2 * trow, xx0 = x0 + 2 * l31;
     // this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel blocks: D register
     // r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half
+    if (vec2) {
+        // Even rows: sixteen aligned float2 outputs per lane.  Everything the epilogue reads
+        // (ReLU mask, style / content terms, bias) is fetched for all sixteen first, from
+        // clamped addresses so that no load sits behind a branch: with the loads inside the
+        // per-output code each output waited for its own round trips to memory and the
+        // epilogue of the shallow layers took longer than their main loop.
+        long idx[16];
+        bool ok[16];
+        int mm[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int i = n >> 3, rr = (n >> 1) & 3, y = n & 1;
+            mm[n] = m0 + i * 32 + rr + 8 * xi + 4 * half;
+            ok[n] = yy + y < a.H && xx0 < a.W && mm[n] < a.M;
+            idx[n] = ok[n] ? (long)mm[n] * HW + (yy + y) * a.W + xx0 : 0;
+        }
+        float2 mk[16], sg[16], ft[16], ct[16];
+        float bs[16];
+        if (EPI == kEpiForward) {
+            if (a.bias) {
+#pragma unroll
+                for (int n = 0; n < 16; n += 2) bs[n] = bs[n + 1] = a.bias[mm[n] < a.M ? mm[n] : 0];
+            }
+        } else if (EPI != kEpiPartial) {
+            if (a.mask) {
+#pragma unroll
+                for (int n = 0; n < 16; ++n) mk[n] = *reinterpret_cast<const float2 *>(a.mask + idx[n]);
+            }
+            if (EPI == kEpiDgradInject) {
+                if (a.inj.sgrad) {
+#pragma unroll
+                    for (int n = 0; n < 16; ++n)
+                        sg[n] = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx[n]);
+                }
+                if (a.inj.content) {
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) {
+                        ft[n] = *reinterpret_cast<const float2 *>(a.inj.feat + idx[n]);
+                        const int cy = ok[n] ? yy + (n & 1) : 0, cx = ok[n] ? xx0 : 0;
+                        const int cm = ok[n] ? mm[n] : 0;
+                        ct[n].x = a.inj.content[content_index(a.inj.win, cm, cy, cx)];
+                        ct[n].y = a.inj.content[content_index(a.inj.win, cm, cy, cx + 1 < a.W ? cx + 1 : cx)];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 16; n += 2) {
+            const int i = n >> 3, rr = (n >> 1) & 3, r = 4 * xi + rr;
+            float2 p[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) p[x] = ex[((trow * 4 + x) * 32 + i * 16 + r) * 64 + lane];
+            float2 o[2] = {make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
+                           make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y)};
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int q = n + y;
+                float2 v = o[y];
+                if (EPI == kEpiPartial) {
+                    if (ok[q]) *reinterpret_cast<float2 *>(a.y + (long)kslice * a.M * HW + idx[q]) = v;
+                    continue;
+                }
+                if (EPI == kEpiForward) {
+                    if (a.bias) v.x += bs[q], v.y += bs[q];
+                    if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+                } else {
+                    if (a.mask) {
+                        v.x = mk[q].x > 0.f ? v.x : 0.f;
+                        v.y = mk[q].y > 0.f ? v.y : 0.f;
+                    }
+                    if (EPI == kEpiDgradInject) {
+                        if (a.inj.content) {
+                            v.x += c_scale * (ft[q].x - ct[q].x);
+                            v.y += c_scale * (ft[q].y - ct[q].y);
+                        }
+                        if (a.inj.sgrad) {
+                            v.x += s_scale * sg[q].x;
+                            v.y += s_scale * sg[q].y;
+                        }
+                    }
+                }
+                if (ok[q]) *reinterpret_cast<float2 *>(a.y + idx[q]) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -429,10 +515,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) p[x] = ex[((trow * 4 + x) * 32 + i * 16 + r) * 64 + lane];
             const int m = m0 + i * 32 + rr + 8 * xi + 4 * half;
-            finish_pair<EPI>(a, vec2, HW, kslice, m, yy, xx0,
+            finish_pair<EPI>(a, false, HW, kslice, m, yy, xx0,
                              make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
                              s_scale, c_scale);
-            finish_pair<EPI>(a, vec2, HW, kslice, m, yy + 1, xx0,
+            finish_pair<EPI>(a, false, HW, kslice, m, yy + 1, xx0,
                              make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y),
                              s_scale, c_scale);
         }
