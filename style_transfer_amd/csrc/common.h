@@ -89,6 +89,9 @@ struct ConvProblem {
     int relu;              // kEpiForward
     int epilogue;
     ConvInject inject;     // kEpiDgrad, optional
+    float *pool_out = nullptr;       // kEpiForward: also write the 2x2/2 ceil-mode pooling of y here
+    int pool_mode = 0;               // (kernels that cannot do it leave it to the caller: see
+                                     // wino2_fuses_pool)
     float *splitk_ws = nullptr;      // scratch for split-K partial sums (optional)
     size_t splitk_ws_floats = 0;
 };
@@ -134,6 +137,8 @@ struct WinoArgs {
     int x_bytes, w_bytes;
     int relu;
     ConvInject inj;
+    float *pool_out;       // forward only: 2x2/2 pooling of the output, or null
+    int pool_mode;
 };
 
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
@@ -151,6 +156,7 @@ size_t wino2_packed_floats(int K, int M);
 int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
                        float *packed);
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+bool wino2_fuses_pool(const ConvProblem &p);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);

@@ -431,6 +431,8 @@ int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int 
     a.w_tile_stride = a.n_chunks * cfg.kc * 12 * cfg.bm;
     a.relu = p.relu;
     a.inj = p.inject;
+    a.pool_out = nullptr;
+    a.pool_mode = 0;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino_packed_floats(cfg, p.K, p.M);
     if (xb >= 2147483648.0 || wb >= 2147483648.0) {

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                 if (EPI == kEpiForward) {
                     if (a.bias) v.x += bs[q], v.y += bs[q];
                     if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+                    o[y] = v;
                 } else {
                     if (a.mask) {
                         v.x = mk[q].x > 0.f ? v.x : 0.f;
@@ -502,6 +503,20 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                     }
                 }
                 if (ok[q]) *reinterpret_cast<float2 *>(a.y + idx[q]) = v;
+            }
+            // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer that
+            // follows (ceil mode: the second row may be missing): pool.hip's arithmetic
+            if (EPI == kEpiForward && a.pool_out && ok[n]) {
+                const bool hy = ok[n + 1];
+                float r;
+                if (a.pool_mode == STX_POOL_MAX) {
+                    r = fmaxf(o[0].x, o[0].y);
+                    if (hy) r = fmaxf(fmaxf(r, o[1].x), o[1].y);
+                } else {
+                    r = (o[0].x + o[0].y + (hy ? o[1].x : 0.f) + (hy ? o[1].y : 0.f)) / (hy ? 4.f : 2.f);
+                }
+                const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
+                a.pool_out[((long)mm[n] * ph + (yy >> 1)) * pw + (xx0 >> 1)] = r;
             }
         }
         return;
@@ -593,6 +608,12 @@ int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int 
     return STX_OK;
 }
 
+// The forward epilogue pools only on its float2 path (even rows, 8-byte aligned arrays).
+bool wino2_fuses_pool(const ConvProblem &p) {
+    return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
+           (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
+}
+
 template <int EPI>
 static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
     auto kern = conv_wino2_kernel<EPI>;
@@ -626,6 +647,8 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.w_tile_stride = a.n_chunks * U_FLOATS;
     a.relu = p.relu;
     a.inj = p.inject;
+    a.pool_out = nullptr;
+    a.pool_mode = p.pool_mode;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);
     if (xb >= 2147483648.0 || wb >= 2147483648.0) {
@@ -645,7 +668,10 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         STX_TRY(wino2_launch_epi<kEpiPartial>(s, a, n_wg));
         return splitk_reduce_launch(s, p, ksplit);
     }
-    if (p.epilogue == kEpiForward) return wino2_launch_epi<kEpiForward>(s, a, n_wg);
+    if (p.epilogue == kEpiForward) {
+        if (wino2_fuses_pool(p)) a.pool_out = p.pool_out;
+        return wino2_launch_epi<kEpiForward>(s, a, n_wg);
+    }
     if (inject) return wino2_launch_epi<kEpiDgradInject>(s, a, n_wg);
     if (p.epilogue == kEpiDgrad) return wino2_launch_epi<kEpiDgrad>(s, a, n_wg);
     set_error("wino2_launch: no kernel for epilogue %d", p.epilogue);

@@ -398,7 +398,15 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
     return conv_launch(e->stream, cfg, p, true);
 }
 
-int run_conv_forward(stx_engine *e, int li, bool force_relu) {
+// True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
+static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
+    return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
+}
+
+// `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
+// the caller whether the convolution wrote its output too.
+int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool = nullptr,
+                     bool *pooled = nullptr) {
     const Layer &L = e->layers[li];
     const Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
@@ -420,6 +428,13 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu) {
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
+    if (pooled) *pooled = false;
+    if (pool) {
+        p.pool_out = e->blobs[pool->top_blob].data.f();
+        p.pool_mode = pool->pool_mode;
+        if (conv_fuses_pool(cfg, p)) *pooled = true;
+        else p.pool_out = nullptr;
+    }
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return launch_conv(e, cfg, p);
 }
@@ -472,13 +487,32 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
 // Runs the layers needed for `needed` blobs, in graph order.  `relu_blob` (or -1) is rectified
 // even when no ReLU layer follows it (np.maximum(0, .) at style_transfer.py:426,567).
 int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
+    int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
         if (L.type == STX_LAYER_RELU || !needed[L.top_blob]) continue;
         const Blob &b = e->blobs[L.bottom_blob];
         Blob &t = e->blobs[L.top_blob];
         if (L.type == STX_LAYER_CONV) {
-            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob));
+            // a 2x2/2 pooling layer fed by this blob (and nothing rectifying the pooled blob,
+            // which would have to come after the pooling) can ride on the convolution's epilogue
+            const Layer *pool = nullptr;
+            int pool_li = -1;
+            for (size_t lj = li + 1; lj < e->layers.size(); ++lj) {
+                const Layer &P = e->layers[lj];
+                if (P.type == STX_LAYER_POOL && P.bottom_blob == L.top_blob && needed[P.top_blob] &&
+                    P.ksize == 2 && P.stride == 2 && P.pad == 0 && !e->blobs[P.top_blob].relu &&
+                    P.top_blob != relu_blob) {
+                    pool = &P;
+                    pool_li = (int)lj;
+                    break;
+                }
+            }
+            bool pooled = false;
+            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled));
+            if (pooled) pooled_layer = pool_li;
+        } else if ((int)li == pooled_layer) {
+            continue;
         } else {
             ProfScope scope(e, "fwd " + L.name, 0.0);
             STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,

@@ -111,7 +111,7 @@ def test_tiled_sc_grad_with_roll_matches_reference_vectors(golden, tag, model):
 
 
 @pytest.mark.parametrize('model', ['vgg19', 'vgg16_avgpool'])
-@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96), (33, 130), (9, 13), (16, 1)])
+@pytest.mark.parametrize('th,tw', [(64, 80), (37, 53), (96, 96), (33, 130), (9, 13), (16, 1), (50, 44)])
 def test_sc_grad_tile_odd_sizes_against_oracle(model, th, tw):
     om, _ = make_oracle(model)
     eng = gpu_engine(model)
