@@ -369,7 +369,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // gets the gaps and runs its tail alone (4630).  s_setprio only swaps the roles; padding
     // either or both waves with s_nop to one MFMA per 128 cycles, alternating priority per
     // k-step, strict ping-pong with two barriers, and the barrier moved between k-steps 2 and 3
-    // were all measured and are no faster.
+    // were all measured and are no faster.  Neither is a persistent variant (workgroups drawing
+    // work items from a ticket counter, first loads of the next item issued before the epilogue
+    // of the current one): the ~6 us a workgroup spends outside its chunk loop are its own
+    // prologue and epilogue, not the ~2 us turnaround of a CU (tools/ubench/launch_gap.hip),
+    // which the dispatcher evidently overlaps.
     int cur = 0;
     int chunk = c_begin;
     long long t_work = 0, t_barrier = 0;
