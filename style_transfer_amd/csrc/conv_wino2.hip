@@ -136,6 +136,7 @@ __device__ __forceinline__ void finish_pair(const WinoArgs &a, bool vec2, int HW
 template <int EPI>
 __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    STX_T(t_start);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = sgpr(tid >> 6);
@@ -387,12 +388,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         t_work += t1 - t0, t_barrier += t2 - t1;
         cur ^= 1;
     }
-#ifdef STX_WINO2_TIMING
-    if (blockIdx.x == 0 && lane == 0) {
-        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = t_barrier;
-        g_wino2_timing[wave][3] = clock64() - t_begin;
-    }
-#endif
+    STX_T(t_main_end);
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
         __syncthreads();
@@ -523,8 +519,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                 a.pool_out[((long)mm[n] * ph + (yy >> 1)) * pw + (xx0 >> 1)] = r;
             }
         }
-        return;
-    }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -541,6 +536,15 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                              make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y),
                              s_scale, c_scale);
         }
+    }
+#ifdef STX_WINO2_TIMING
+    if (blockIdx.x == 0 && lane == 0) {
+        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = t_barrier;
+        g_wino2_timing[wave][3] = t_main_end - t_begin;
+        g_wino2_timing[wave][4] = t_begin - t_start;
+        g_wino2_timing[wave][5] = clock64() - t_main_end;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -53,9 +53,9 @@ static void run(int K, int M, int H, int W, int epilogue) {
     long long t[8][8];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
     const int chunks = (K + 7) / 8 - 2;
-    for (int wv = 0; wv < 8; ++wv)
-        printf("   wave %d: per chunk  work %6.0f  barrier %6.0f   total %7.0f cycles\n", wv,
-               (double)t[wv][0] / chunks, (double)t[wv][2] / chunks, (double)t[wv][3] / chunks);
+    for (int wv = 0; wv < 8; wv += 4)
+        printf("   wave %d: per chunk  work %6.0f  barrier %6.0f   |  prologue %6lld  chunk loop %7lld  epilogue %6lld cycles\n", wv,
+               (double)t[wv][0] / chunks, (double)t[wv][2] / chunks, t[wv][4], t[wv][3], t[wv][5]);
 #endif
     hipFree(x), hipFree(y), hipFree(w), hipFree(mask);
 }
