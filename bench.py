@@ -61,10 +61,10 @@ def smooth_picture(seed, h, w):
 
 def measured_traffic():
     """HBM bytes per stx_sc_grad_tile launch from the PMC passes of this build
-    (profiles/r01_h_hbm_traffic_pmc.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    (profiles/r01_i_hbm_traffic_pmc.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
     separate runs of this script, FETCH_SIZE doubled per the gfx950 calibration on the Adam
     kernel -- tools/pmc_traffic.py).  None if the file is missing."""
-    path = os.path.join(REPO, 'profiles', 'r01_h_hbm_traffic_pmc.json')
+    path = os.path.join(REPO, 'profiles', 'r01_i_hbm_traffic_pmc.json')
     try:
         with open(path) as f:       # measured per tile-iteration; one launch group = 4 of them
             return float(json.load(f)['hbm_bytes_per_tile_iteration']) * TILES_PER_GPU
