@@ -321,7 +321,7 @@ static const WinoVariant kWino[] = {
 };
 
 ConvConfig wino_config_by_id(int id) {
-    if (id >= 100) return wino2_config();
+    if (id >= 100) return wino2_config(id - 100);
     const WinoVariant &v = kWino[id];
     ConvConfig c;
     c.id = 100 + id;                  // ids >= 100 mark Winograd configurations

@@ -58,7 +58,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int KC = 8, BM = 64, NT = 512, PR = 4, PC = 64;
+constexpr int KC = 8, BM = 64, NT = 512;
+// Pixel patch of a workgroup = 64 tiles.  TXW = tiles per tile row within a wave's 32: 32 -> 4 rows x
+// 64 columns (long row segments for loads and stores), 8 -> 16 x 16 pixels (planes whose width is
+// not near a multiple of 64, e.g. the 91 x 91 / 46 x 46 planes of a 724-pixel tile).
+template <int TXW>
+struct Geo {
+    static constexpr int TYW = 32 / TXW;          // tile rows per wave
+    static constexpr int PR = 4 * TYW, PC = 2 * TXW;
+};
 constexpr int U_FLOATS = 4 * KC * BM * 4;     // [xi][ci][m][nu]
 constexpr int V_FLOATS = 4 * KC * 64 * 4;     // [xi][ci][tile][nu]
 constexpr int STAGE = U_FLOATS + V_FLOATS;    // 64 KB
@@ -133,8 +141,9 @@ __device__ __forceinline__ void finish_pair(const WinoArgs &a, bool vec2, int HW
 
 }  // namespace
 
-template <int EPI>
+template <int EPI, int TXW>
 __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
+    constexpr int TYW = Geo<TXW>::TYW, PR = Geo<TXW>::PR, PC = Geo<TXW>::PC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     STX_T(t_start);
 
@@ -176,12 +185,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // still has a column inside (tiles entirely outside compute garbage nobody stores).
     // The one patch row whose x = -1 would lie before the start of the tensor (channel 0, row 0
     // of the first workgroup) is loaded from x = 0 and shifted by one instead.
-    const int st_x = x0 + 2 * (lane & 31) - 1;            // first patch column
+    const int st_x = x0 + 2 * (lane % TXW) - 1;           // first patch column
     const bool left = st_x < 0;
     const bool corner = wave == 0 && y0 == 0 && x0 == 0;  // uniform: lane 0, patch row 1
     unsigned xvoff[4];
     {
-        const int ty = lane >> 5;
+        const int ty = lane / TXW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = y0 + 2 * ty - 1 + i;
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     }
     const bool vec2 = ((a.W & 1) | (((size_t)a.y | (size_t)a.mask | (size_t)a.inj.feat |
                                      (size_t)a.inj.sgrad) & 7)) == 0;
-    const int yy = y0 + 2 * trow, xx0 = x0 + 2 * l31;
+    const int yy = y0 + 2 * (trow * TYW + l31 / TXW), xx0 = x0 + 2 * (l31 % TXW);
     // this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel blocks: D register
     // r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half
     if (vec2) {
@@ -548,16 +557,27 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-ConvConfig wino2_config() {
+ConvConfig wino2_config(int geometry) {
     ConvConfig c;
-    c.id = 200;                       // ids >= 200 mark the 2-D Winograd configuration
+    c.id = 200 + geometry;            // ids >= 200 mark the 2-D Winograd configurations
     c.bm = BM;
     c.kc = KC;
-    c.pr = PR;
-    c.pc = PC;
+    c.pr = geometry ? Geo<8>::PR : Geo<32>::PR;
+    c.pc = geometry ? Geo<8>::PC : Geo<32>::PC;
     c.threads = NT;
     c.lds_bytes = kLdsBytes;
     return c;
+}
+
+// 16 x 16 patches for narrow planes, where a 64-pixel-wide patch is mostly padding (measured:
+// a 256 x 256 tile 1.50 -> 1.36 ms); from 46 pixels up the wide patch is as fast or faster
+// (its loads and stores are long row segments, and the smaller workgroup count of the square
+// geometry buys nothing once the K split has evened out the last round).  Both geometries
+// compute every output with the same arithmetic in the same order: the choice never changes
+// a result.
+int wino2_pick_geometry(int H, int W) {
+    (void)H;
+    return W <= 40 ? 1 : 0;
 }
 
 size_t wino2_packed_floats(int K, int M) {
@@ -622,9 +642,9 @@ bool wino2_fuses_pool(const ConvProblem &p) {
            (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
-template <int EPI>
+template <int EPI, int TXW>
 static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_wino2_kernel<EPI>;
+    auto kern = conv_wino2_kernel<EPI, TXW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
@@ -648,8 +668,8 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.H = p.H;
     a.W = p.W;
     a.n_chunks = ceil_div(p.K, KC);
-    a.tiles_x = ceil_div(p.W, PC);
-    a.tiles_y = ceil_div(p.H, PR);
+    a.tiles_x = ceil_div(p.W, cfg.pc);
+    a.tiles_y = ceil_div(p.H, cfg.pr);
     a.m_tiles = ceil_div(p.M, BM);
     a.ksplit = 1;
     a.w_tile_stride = a.n_chunks * U_FLOATS;
@@ -673,17 +693,26 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         a.ksplit = ksplit;
         a.y = p.splitk_ws;
         n_wg *= ksplit;
-        STX_TRY(wino2_launch_epi<kEpiPartial>(s, a, n_wg));
-        return splitk_reduce_launch(s, p, ksplit);
+    } else if (p.epilogue == kEpiForward && wino2_fuses_pool(p)) {
+        a.pool_out = p.pool_out;
     }
-    if (p.epilogue == kEpiForward) {
-        if (wino2_fuses_pool(p)) a.pool_out = p.pool_out;
-        return wino2_launch_epi<kEpiForward>(s, a, n_wg);
+    const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
+#define STX_W2_CASE(E)                                                                            \
+    case E:                                                                                       \
+        STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8>(s, a, n_wg))                              \
+                              : (wino2_launch_epi<E, 32>(s, a, n_wg)));                           \
+        break;
+    switch (epi) {
+        STX_W2_CASE(kEpiForward)
+        STX_W2_CASE(kEpiDgrad)
+        STX_W2_CASE(kEpiDgradInject)
+        STX_W2_CASE(kEpiPartial)
+        default:
+            set_error("wino2_launch: no kernel for epilogue %d", p.epilogue);
+            return STX_ERR_UNSUPPORTED;
     }
-    if (inject) return wino2_launch_epi<kEpiDgradInject>(s, a, n_wg);
-    if (p.epilogue == kEpiDgrad) return wino2_launch_epi<kEpiDgrad>(s, a, n_wg);
-    set_error("wino2_launch: no kernel for epilogue %d", p.epilogue);
-    return STX_ERR_UNSUPPORTED;
+#undef STX_W2_CASE
+    return split ? splitk_reduce_launch(s, p, ksplit) : STX_OK;
 }
 
 }  // namespace stx

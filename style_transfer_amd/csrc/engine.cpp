@@ -282,7 +282,7 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
     }
-    const int key = dir * 1024 + cfg.id;
+    const int key = dir * 1024 + (cfg.id >= 200 ? 200 : cfg.id);   // both 2-D geometries share a bank
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
         const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
@@ -317,16 +317,17 @@ static std::map<std::vector<int>, int> g_tuned;
 // and a given shape must always take the same path.  STX_CONV_ALGO=direct|wino1|wino2 (read at
 // every call) overrides it for tests and measurements.
 static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out) {
-    (void)H, (void)W;
     if (ksize != 3 || K < 8 || M <= 4) return false;
     const char *algo = getenv("STX_CONV_ALGO");
     if (algo && *algo) {
         if (!strcmp(algo, "direct")) return false;
-        if (!strcmp(algo, "wino2")) { *out = wino_config_by_id(100); return true; }
+        if (!strcmp(algo, "wino2")) { *out = wino2_config(wino2_pick_geometry(H, W)); return true; }
+        if (!strcmp(algo, "wino2a")) { *out = wino2_config(0); return true; }   // one geometry only
+        if (!strcmp(algo, "wino2b")) { *out = wino2_config(1); return true; }
         if (!strcmp(algo, "wino1")) { *out = wino_config_by_id(M >= 64 ? 0 : 1); return true; }
     }
     if (!e->winograd) return false;
-    *out = M > 32 ? wino_config_by_id(100) : wino_config_by_id(1);
+    *out = M > 32 ? wino2_config(wino2_pick_geometry(H, W)) : wino_config_by_id(1);
     return true;
 }
 

@@ -34,7 +34,7 @@ static void run(int K, int M, int H, int W, int epilogue) {
     ConvProblem p{};
     p.x = x, p.w = w, p.y = y, p.bias = nullptr, p.mask = epilogue == kEpiDgrad ? mask : nullptr;
     p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = 1, p.epilogue = epilogue;
-    const ConvConfig cfg = wino2_config();
+    const ConvConfig cfg = wino2_config(getenv("GEO") ? atoi(getenv("GEO")) : wino2_pick_geometry(H, W));
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) wino2_launch(0, cfg, p, 1);
