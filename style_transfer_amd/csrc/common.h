@@ -158,6 +158,7 @@ int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int 
                        float *packed);
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 bool wino2_fuses_pool(const ConvProblem &p);
+int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);

@@ -580,6 +580,30 @@ int wino2_pick_geometry(int H, int W) {
     return W <= 40 ? 1 : 0;
 }
 
+// K split of a launch.  One workgroup per CU and ~6 us of prologue + epilogue per workgroup make
+// the small-tile rule of conv_mfma.hip wrong here (it sliced the 8 chunks of a 64-channel layer
+// in two: 0.167 ms where the unsplit launch takes 0.11).  The factor minimises a cost model of
+// whole rounds of 256 workgroups -- chunks x 2.05 us + 6 us each -- plus the reduce pass over
+// the slices; it depends on the shape only.
+int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
+    if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return 1;
+    const int n_chunks = ceil_div(p.K, KC);
+    const long n = (long)ceil_div(p.M, BM) * ceil_div(p.H, cfg.pr) * ceil_div(p.W, cfg.pc);
+    const double out_mb = 4e-6 * p.M * (double)p.H * p.W;
+    double best_cost = 0;
+    int best = 1;
+    for (int f = 1; f <= 8 && n_chunks / f >= 4; ++f) {
+        const double rounds = (double)ceil_div((int)std::min<long>(n * f, 1 << 30), 256);
+        double cost = rounds * ((double)n_chunks / f * 2.05 + 6.0);
+        if (f > 1) cost += (f + 1) * out_mb / 3.0 + 5.0;      // reduce pass at ~3 TB/s + its launch
+        if (f == 1 || cost < best_cost) {
+            best_cost = cost;
+            best = f;
+        }
+    }
+    return best;
+}
+
 size_t wino2_packed_floats(int K, int M) {
     return (size_t)ceil_div(M, BM) * ceil_div(K, KC) * U_FLOATS;
 }
