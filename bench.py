@@ -187,20 +187,32 @@ def main():
                      opt=AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05,
                                        power=0.5))
 
-    def evaluate(jobs, roll):
-        """Runs this rank's tiles concurrently, one per engine; [(loss, grad tensor)]."""
-        pend = []
+    inflight = []
+
+    def evaluate_begin(jobs, roll):
+        """Enqueues this rank's tiles, one per engine (they run concurrently)."""
+        inflight.clear()
         for k, (tile, start) in enumerate(jobs):
             e = engines[k % len(engines)]
             g = grad_bufs[k]
-            pend.append(e.sc_grad_tile_async(wrap(tile, e), start, roll, CONTENT_LAYERS,
-                                             STYLE_LAYERS, {}, content_weight, style_weight,
-                                             grad_out=wrap(g, e)))
-        used = engines[:min(len(jobs), len(engines))]
+            inflight.append((e, k, e.sc_grad_tile_async(
+                wrap(tile, e), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {}, content_weight,
+                style_weight, grad_out=wrap(g, e))))
+
+    def evaluate_end():
+        """Waits for them; [(loss, grad tensor)]."""
+        used = []
+        for e, _, _ in inflight:
+            if e not in used:
+                used.append(e)
         for e in used:
             e.sync()
         group_ms.append(max(e.last_tile_ms() for e in used))
-        return [(p.loss, grad_bufs[k]) for k, p in enumerate(pend)]
+        return [(p.loss, grad_bufs[k]) for _, k, p in inflight]
+
+    def evaluate(jobs, roll):
+        evaluate_begin(jobs, roll)
+        return evaluate_end()
 
     grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
                  for _ in range(TILES_PER_GPU)]
@@ -217,8 +229,8 @@ def main():
         image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g, eng))
 
     if world > 1:
-        farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0], evaluate, put,
-                                device)
+        farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0],
+                                (evaluate_begin, evaluate_end), put, device)
 
     def eval_sc_grad(roll):
         if world > 1:

@@ -29,10 +29,19 @@ import torch.distributed as dist
 class DistributedTiles:
     """cut(rect, roll) -> tensor[3,th,tw] on rank 0; evaluate(jobs, roll) with
     jobs = [(tile tensor, (y0, x0)), ...] -> [(loss, grad tensor), ...] on every rank;
-    put(rect, grad, roll) on rank 0.  All tensors live on ``device``."""
+    put(rect, grad, roll) on rank 0.  All tensors live on ``device``.
+
+    ``evaluate`` may also be a pair (begin, end): begin(jobs, roll) enqueues the work without
+    waiting and end() -> [(loss, grad tensor), ...] waits for it.  Rank 0 then starts its own
+    tiles while its sends to the other ranks are still in flight."""
 
     def __init__(self, cut, evaluate, put, device, group=None):
-        self.cut, self.evaluate, self.put = cut, evaluate, put
+        self.cut, self.put = cut, put
+        if callable(evaluate):
+            self.evaluate, self.evaluate_begin, self.evaluate_end = evaluate, None, None
+        else:
+            self.evaluate_begin, self.evaluate_end = evaluate
+            self.evaluate = lambda jobs, roll: (self.evaluate_begin(jobs, roll), self.evaluate_end())[1]
         self.device = torch.device(device)
         self.group = group
         self.rank = dist.get_rank(group)
@@ -83,25 +92,40 @@ class DistributedTiles:
         tiles = {}
         ops = []
         if self.rank == 0:
+            own = [t for t in range(len(rects)) if owner[t] == 0]
+            # peers' tiles first, so that they leave while this rank cuts and starts its own
             for t, rect in enumerate(rects):
-                tile = self.cut(rect, roll)
-                if owner[t] == 0:
-                    tiles[t] = tile
-                else:
-                    ops.append(dist.P2POp(dist.isend, self._out(tile), owner[t], self.group))
+                if owner[t] != 0:
+                    ops.append(dist.P2POp(dist.isend, self._out(self.cut(rect, roll)), owner[t],
+                                          self.group))
             self._sync()
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            for t in own:
+                tiles[t] = self.cut(rects[t], roll)
+            jobs = [(tiles[t], (rects[t][0], rects[t][2])) for t in mine]
+            if self.evaluate_begin is not None and jobs:
+                # no device-wide synchronisation here (it would wait for the sends): with a
+                # two-phase evaluate, cut() must hand back finished tensors or run on the stream
+                # evaluate_begin enqueues to
+                self.evaluate_begin(jobs, roll)          # overlaps the sends
+                for req in reqs:
+                    req.wait()
+                results = self.evaluate_end()
+            else:
+                for req in reqs:
+                    req.wait()
+                self._sync()
+                results = self.evaluate(jobs, roll) if jobs else []
         else:
             for t in mine:
                 tiles[t] = self._buffer(('tile', t), shape(t))
                 ops.append(dist.P2POp(dist.irecv, tiles[t], 0, self.group))
-        self._run(ops)
-        if self.rank != 0:
+            self._run(ops)
             tiles = {t: self._in(buf) for t, buf in tiles.items()}
-        self._sync()
-
-        # ---- evaluate the local tiles (possibly concurrently, that is the callee's business)
-        results = self.evaluate([(tiles[t], (rects[t][0], rects[t][2])) for t in mine], roll) \
-            if mine else []
+            self._sync()
+            # ---- evaluate the local tiles (possibly concurrently, that is the callee's business)
+            results = self.evaluate([(tiles[t], (rects[t][0], rects[t][2])) for t in mine], roll) \
+                if mine else []
         self._sync()
 
         # ---- gather

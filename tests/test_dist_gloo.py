@@ -31,7 +31,7 @@ def _problem():
     return img, style, cl, cw, sl, sw
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, two_phase=False):
     from style_transfer_amd.dist import DistributedTiles, broadcast_targets
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -63,7 +63,15 @@ def _worker(rank, world, port, out_path):
     def put(rect, g, r):
         grad[:, rect[0]:rect[1], rect[2]:rect[3]] = g.numpy()
 
-    farm = DistributedTiles(cut, evaluate, put, 'cpu')
+    pending = {}
+
+    def begin(jobs, r):              # the two-phase form: rank 0 overlaps its sends with this
+        pending['args'] = (jobs, r)
+
+    def end():
+        return evaluate(*pending.pop('args'))
+
+    farm = DistributedTiles(cut, (begin, end) if two_phase else evaluate, put, 'cpu')
     rects = tile_grid(img.shape[-2:], 32)
     loss = farm.eval_sc_grad(rects, roll if rank == 0 else (0, 0))
     if rank == 0:
@@ -73,9 +81,10 @@ def _worker(rank, world, port, out_path):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_tile_farm_equals_single_process(tmp_path):
+@pytest.mark.parametrize('two_phase', [False, True])
+def test_two_rank_tile_farm_equals_single_process(tmp_path, two_phase):
     out = str(tmp_path / 'dist.npz')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, two_phase), nprocs=2, join=True)
     got = np.load(out)
     img, style, cl, cw, sl, sw = _problem()
     om, _ = make_oracle('vgg16_avgpool')
