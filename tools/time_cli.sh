@@ -14,3 +14,8 @@ run() {
 run "adam --size 1024 --tile-size 1024" --size 1024 --tile-size 1024 -oi /tmp/stx_out_1024.png
 run "adam --size 2048 --tile-size 1024" --size 2048 --tile-size 1024 -oi /tmp/stx_out_2048.png
 run "lbfgs --size 2048 --tile-size 1024 -i 100" --size 2048 --tile-size 1024 -o lbfgs -i 100 -oi /tmp/stx_out_l.png
+if [ "$1" = "all" ]; then
+    python "$REPO/tools/make_inputs.py" /tmp/stx_in 4096 >/dev/null
+    run "config 4: lbfgs --size 4096 --tile-size 1024" --size 4096 --tile-size 1024 -o lbfgs -oi /tmp/stx_out_c4.png
+    run "config 5: vgg16_avgpool, two styles, --size 2048" --size 2048 --tile-size 1024 --model vgg16_avgpool.prototxt -si /tmp/stx_in/style.png /tmp/stx_in/content.png -oi /tmp/stx_out_c5.png
+fi
