@@ -10,6 +10,7 @@ This module reproduces the coefficient tables on the host (a few KB) and lets
 """
 
 import ctypes
+import functools
 import math
 
 import numpy as np
@@ -35,8 +36,10 @@ def _triangle(x):
 _FILTERS = {LANCZOS: (_lanczos, 3.0), BILINEAR: (_triangle, 1.0)}
 
 
+@functools.lru_cache(maxsize=64)
 def coefficients(in_size, out_size, method):
-    """(bounds int32 [out, 2] = (first input index, tap count), weights float64 [out, ksize])."""
+    """(bounds int32 [out, 2] = (first input index, tap count), weights float64 [out, ksize]).
+    Cached: a scale change resamples four arrays with the same two tables; treat as read-only."""
     filt, base_support = _FILTERS[method]
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
