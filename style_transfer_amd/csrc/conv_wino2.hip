@@ -388,13 +388,21 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     int chunk = c_begin;
     long long t_work = 0, t_barrier = 0;
     STX_T(t_begin);
-    for (; chunk + 2 < c_end; ++chunk) {
+    // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
+    // of the hand-over and of the operand reads is a register plus an immediate
+    for (; chunk + 3 < c_end; chunk += 2) {
         STX_T(t0);
-        run_chunk(cur, chunk, yes{}, yes{});
+        run_chunk(0, chunk, yes{}, yes{});
+        __syncthreads();
+        run_chunk(1, chunk + 1, yes{}, yes{});
         STX_T(t1);
         __syncthreads();
         STX_T(t2);
         t_work += t1 - t0, t_barrier += t2 - t1;
+    }
+    for (; chunk + 2 < c_end; ++chunk) {
+        run_chunk(cur, chunk, yes{}, yes{});
+        __syncthreads();
         cur ^= 1;
     }
     STX_T(t_main_end);
