@@ -188,6 +188,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int st_x = x0 + 2 * (lane % TXW) - 1;           // first patch column
     const bool left = st_x < 0;
     const bool corner = wave == 0 && y0 == 0 && x0 == 0;  // uniform: lane 0, patch row 1
+    const bool corner_lane = lane == 0;
     unsigned xvoff[4];
     {
         const int ty = lane / TXW;
@@ -237,10 +238,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xreg[i]));
         if (corner) {
-            const bool c = lane == 0;
-            xreg[1].w = c ? xreg[1].z : xreg[1].w;
-            xreg[1].z = c ? xreg[1].y : xreg[1].z;
-            xreg[1].y = c ? xreg[1].x : xreg[1].y;
+            asm volatile("");      // keeps this a (scalar) branch: one wave in the whole launch takes it
+            // plain floats: element assignments through a select turn into dynamic indexing
+            const float r0 = xreg[1].x, r1 = xreg[1].y, r2 = xreg[1].z, r3 = xreg[1].w;
+            xreg[1].y = corner_lane ? r0 : r1;
+            xreg[1].z = corner_lane ? r1 : r2;
+            xreg[1].w = corner_lane ? r2 : r3;
         }
         if (edge_l) {
 #pragma unroll
