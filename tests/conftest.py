@@ -19,3 +19,12 @@ def golden():
     path = os.path.join(REPO, 'tests', 'golden', 'reference_vectors.npz')
     z = np.load(path)
     return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(autouse=True)
+def _gpu_guard(request):
+    """Every test marked `gpu` needs a device: skipped on machines without an AMD GPU driver
+    node, a failure on the GPU box (tests/gpu_helpers.require_gpu)."""
+    if request.node.get_closest_marker('gpu') is not None:
+        from tests.gpu_helpers import require_gpu
+        require_gpu()

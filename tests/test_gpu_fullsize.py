@@ -1,0 +1,172 @@
+"""Parity at the sizes the benchmark and BASELINE.json's configurations actually run.
+
+The other GPU tests use planes of at most 130 x 129; the headline runs 1024 x 1024 tiles, the
+2048-pixel pyramid also produces 724 x 724 tiles and config 4's 2896 scale 965/966-pixel ones.
+Large planes reach code small ones never do: the K-split cost model over whole rounds of 256
+workgroups, the XCD work order with thousands of workgroups, Gram split-K over 2^20 pixels,
+pooling backward on 268 MB blobs, both Winograd patch geometries down one stack, the unfused
+pooling path when a plane's width is odd.  Everything here goes through the C ABI and is
+compared with the numpy oracle (tests/gpu_helpers.check_tile: activations / loss / gradient
+with identical decisions at 1e-5 of max, located decision flips for the rest).
+
+Per-kernel cases at the real layer shapes use the same 2e-5 bound as tests/test_gpu_kernels.py.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import layers as L
+from oracle import num_ops
+from style_transfer_amd import lib
+from tests.gpu_helpers import check_tile, gpu_engine, max_rel
+from tests.helpers import DEFAULT_STYLE_LAYERS, make_oracle, normalized_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth(rng, h, w):
+    """Picture-like input: low-pass noise plus fine noise, BGR minus mean range."""
+    coarse = rng.uniform(-110, 120, (3, h // 16 + 2, w // 16 + 2)).astype(np.float32)
+    img = np.repeat(np.repeat(coarse, 16, axis=1), 16, axis=2)[:, :h, :w]
+    return np.ascontiguousarray(img + rng.uniform(-16, 16, (3, h, w)).astype(np.float32))
+
+
+def _random_targets(om, rng, img_hw, content_layers, style_layers):
+    """Targets of the right shapes without running the oracle over a full image: the tile path
+    only reads them (content window + roll addressing, lower-triangular Gram)."""
+    contents = {}
+    for l in content_layers:
+        s, c = om.scale[l], om.channels[l]
+        shape = (c, -(-img_hw[0] // s), -(-img_hw[1] // s))
+        contents[l] = np.abs(rng.standard_normal(shape)).astype(np.float32)
+    styles = {l: np.tril(0.05 * rng.standard_normal((om.channels[l],) * 2)).astype(np.float32)
+              for l in style_layers}
+    return [contents], [styles]
+
+
+# (tile h, tile w, image h, image w, start, roll): the benchmark tile; the 724^2 tiles of the
+# 1448 scale; the ragged 965 x 966 corner tile of the 2896 scale (style_transfer.py:619-632)
+TILE_CASES = [
+    (1024, 1024, 2048, 2048, (1024, 0), (-312, 200)),
+    (724, 724, 1448, 1448, (724, 724), (64, -128)),
+    (965, 966, 2896, 2896, (1930, 965), (-8, 1024)),
+]
+
+
+@pytest.mark.parametrize('th,tw,ih,iw,start,roll', TILE_CASES)
+def test_sc_grad_tile_at_benchmark_sizes(th, tw, ih, iw, start, roll):
+    om, _ = make_oracle('vgg19')
+    eng = gpu_engine('vgg19')
+    rng = np.random.RandomState(th + tw)
+    cl, cw = normalized_weights(['conv4_2'], 0.05)
+    sl, sw = normalized_weights(DEFAULT_STYLE_LAYERS, 1)
+    om.contents, om.styles = _random_targets(om, rng, (ih, iw), cl, sl)
+    eng.set_contents_and_styles(om.contents, om.styles)
+    tile = _smooth(rng, th, tw)
+    _, _, stats = check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, {})
+    print('%dx%d tile: %s, %.2f ms on the GPU' % (th, tw, stats, eng.last_tile_ms()))
+
+
+def test_sc_grad_tile_vgg16_avgpool_at_1024():
+    """Config 5's network at the benchmark tile size, two style targets (averaged Grams are the
+    host's business; the engine sees n_styles = 2 separate sets)."""
+    om, _ = make_oracle('vgg16_avgpool')
+    eng = gpu_engine('vgg16_avgpool')
+    rng = np.random.RandomState(5)
+    cl, cw = normalized_weights(['conv4_2'], 0.05)
+    sl, sw = normalized_weights(DEFAULT_STYLE_LAYERS, 1)
+    om.contents, om.styles = _random_targets(om, rng, (2048, 2048), cl, sl)
+    om.styles.append(_random_targets(om, rng, (8, 8), [], sl)[1][0])
+    eng.set_contents_and_styles(om.contents, om.styles)
+    tile = _smooth(rng, 1024, 1024)
+    _, _, stats = check_tile(eng, om, tile, (0, 1024), (16, 16), cl, cw, sl, sw, {}, flip_l2=1e-3)
+    print('vgg16_avgpool 1024x1024:', stats)
+
+
+# ---------------------------------------------------------------------------- single kernels
+# (Cin, Cout, H, W) of VGG-19 layers inside a 1024 x 1024 tile: conv1_2, conv2_2, conv3_2,
+# conv4_2, conv5_1 (K split on), and the two odd-plane relatives of a 724-pixel tile
+REAL_CONV_SHAPES = [(64, 64, 1024, 1024), (128, 128, 512, 512), (256, 256, 256, 256),
+                    (512, 512, 128, 128), (512, 512, 64, 64), (128, 128, 362, 362),
+                    (256, 512, 91, 91)]
+
+
+@pytest.mark.parametrize('cin,cout,h,w', REAL_CONV_SHAPES)
+def test_conv_at_real_layer_shapes(cin, cout, h, w):
+    eng = gpu_engine()
+    rng = np.random.RandomState(cin + h)
+    x = np.maximum(rng.standard_normal((cin, h, w)), 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2 / (9 * cin))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    dx_, dw, db = eng.to_device(x), eng.to_device(wt), eng.to_device(b)
+    y = eng.empty((cout, h, w))
+    lib.call('stx_op_conv_forward', eng.handle, dx_.ptr, cin, h, w, dw.ptr, db.ptr, cout, 3, 1,
+             y.ptr)
+    ref = np.maximum(L.conv_forward(x, wt, b), 0)
+    assert max_rel(y.get(), ref) < 2e-5
+    del ref
+    dy = rng.standard_normal((cout, h, w)).astype(np.float32)
+    ddy, gx = eng.to_device(dy), eng.empty((cin, h, w))
+    lib.call('stx_op_conv_backward_data', eng.handle, ddy.ptr, cout, h, w, dw.ptr, cin, 3,
+             dx_.ptr, gx.ptr)
+    ref = L.conv_backward_data(dy, wt) * (x > 0)
+    assert max_rel(gx.get(), ref) < 2e-5
+    for a in (dx_, dw, db, y, ddy, gx):
+        a.free()
+
+
+def test_first_and_last_layer_at_1024():
+    """conv1_1 forward (3 -> 64, direct kernel) and its backward into the image (64 -> 3, the
+    4x4x1-MFMA kernel) on a 1024 x 1024 plane."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(1)
+    h = w = 1024
+    x = rng.uniform(-110, 120, (3, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((64, 3, 3, 3)) * np.sqrt(2 / 27)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(64)).astype(np.float32)
+    dx_, dw, db = eng.to_device(x), eng.to_device(wt), eng.to_device(b)
+    y = eng.empty((64, h, w))
+    lib.call('stx_op_conv_forward', eng.handle, dx_.ptr, 3, h, w, dw.ptr, db.ptr, 64, 3, 1, y.ptr)
+    assert max_rel(y.get(), np.maximum(L.conv_forward(x, wt, b), 0)) < 2e-5
+    dy = rng.standard_normal((64, h, w)).astype(np.float32)
+    ddy, gx = eng.to_device(dy), eng.empty((3, h, w))
+    lib.call('stx_op_conv_backward_data', eng.handle, ddy.ptr, 64, h, w, dw.ptr, 3, 3, None,
+             gx.ptr)
+    assert max_rel(gx.get(), L.conv_backward_data(dy, wt)) < 2e-5
+    for a in (dx_, dw, db, y, ddy, gx):
+        a.free()
+
+
+@pytest.mark.parametrize('c,h,w', [(64, 1024, 1024), (128, 512, 512), (512, 64, 64),
+                                   (256, 181, 181)])
+def test_gram_at_real_layer_shapes(c, h, w):
+    """K = 2^20 pixels with 64 channels (512 split slices) down to C = 512, K = 4096."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(c)
+    feat = np.maximum(rng.standard_normal((c, h, w)), 0).astype(np.float32)
+    gram = eng.gram_matrix(feat)
+    assert np.all(np.triu(gram, 1) == 0)
+    f64 = feat.reshape(c, -1).astype(np.float64)
+    ref = np.tril(f64 @ f64.T / feat.size)
+    assert max_rel(gram, ref) < 2e-5
+    assert max_rel(num_ops.gram_lower(feat), ref) < 2e-5      # the oracle itself, same bound
+
+
+@pytest.mark.parametrize('mode', ['MAX', 'AVE'])
+@pytest.mark.parametrize('c,h,w', [(64, 1024, 1024), (128, 483, 483)])
+def test_pooling_at_real_layer_shapes(c, h, w, mode):
+    eng = gpu_engine()
+    rng = np.random.RandomState(h)
+    x = np.maximum(rng.standard_normal((c, h, w)), 0).astype(np.float32)
+    code = lib.POOL_MAX if mode == 'MAX' else lib.POOL_AVE
+    ref, aux = L.pool_forward(x, mode)
+    dx_, y = eng.to_device(x), eng.empty(ref.shape)
+    lib.call('stx_op_pool_forward', eng.handle, dx_.ptr, c, h, w, code, y.ptr)
+    assert np.array_equal(y.get(), ref) if mode == 'MAX' else max_rel(y.get(), ref) < 1e-6
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    ddy, gx = eng.to_device(dy), eng.empty(x.shape)
+    lib.call('stx_op_pool_backward', eng.handle, ddy.ptr, dx_.ptr, c, h, w, code, dx_.ptr, gx.ptr)
+    gref = L.pool_backward(dy, x.shape, aux, mode) * (x > 0)
+    assert max_rel(gx.get(), gref) < 1e-6
+    for a in (dx_, y, ddy, gx):
+        a.free()
