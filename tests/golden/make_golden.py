@@ -321,6 +321,90 @@ def main():
     out['e2e_lbfgs/log'] = np.float64(log)
     out['e2e_lbfgs/final_raw'] = transfer.current_raw.copy()
 
+    # ------- 4c. BASELINE config 4 in miniature: VGG-19 (MAX pooling) x L-BFGS x a 3 x 3 tiling
+    # whose last row / column is larger (style_transfer.py:619-632), two scales.  The step lines
+    # the reference's own Progress prints (style_transfer.py:950-951), its CSV log
+    # (style_transfer.py:121-130) and its PNG comment (style_transfer.py:1003-1010) are kept too.
+    import contextlib
+    import io
+    import tempfile
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png', '--size', '100',
+                '--min-size', '64', '--tile-size', '40', '--iterations', '3', '2', '-o', 'lbfgs',
+                '--display', 'none', '--seed', '13', '--save-every', '2']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(60, 92, 100)
+    style_u8 = smooth_image(61, 80, 70)
+    log = []
+    tmp = tempfile.mkdtemp()
+    st.RUN = os.path.join(tmp, 'run')
+    web_if = types.SimpleNamespace(put_event=lambda ev: None)
+    progress = st.Progress(transfer, save_every=st.ARGS.save_every, web_if=web_if,
+                           callback=None)
+    saved = []
+
+    def cb(**kw):
+        log.append((kw['step'], kw['update_size'], kw['loss'], kw['tv_loss']))
+        progress(**kw)
+    cb.set_steps = progress.set_steps
+    np.random.seed(st.ARGS.seed)
+    stdout = io.StringIO()
+    with contextlib.redirect_stdout(stdout):
+        transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                     None, None, callback=cb)
+    st.STATS.dump()
+    with open(st.RUN + '_log.csv') as f:
+        csv_lines = f.read().splitlines()
+    saved = sorted(n[len('run'):] for n in os.listdir(tmp) if n.endswith('.png'))
+    out['e2e_cfg4/content_u8'], out['e2e_cfg4/style_u8'] = content_u8, style_u8
+    out['e2e_cfg4/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e_cfg4/log'] = np.float64(log)
+    out['e2e_cfg4/final_raw'] = transfer.current_raw.copy()
+    out['e2e_cfg4/final_u8'] = np.asarray(transfer.current_output)
+    out['e2e_cfg4/step_lines'] = np.array('\n'.join(
+        l for l in stdout.getvalue().splitlines() if l.startswith('Step ')))
+    out['e2e_cfg4/tile_lines'] = np.array('\n'.join(
+        l for l in stdout.getvalue().splitlines() if l.startswith('Using ')))
+    out['e2e_cfg4/csv_header'] = np.array(csv_lines[0])
+    out['e2e_cfg4/csv_rows'] = np.array('\n'.join(csv_lines[1:]))
+    out['e2e_cfg4/saved_files'] = np.array(' '.join(saved))
+    out['e2e_cfg4/image_comment'] = np.array(st.get_image_comment())
+
+    # ----------- 4d. the six deploy prototxts the reference ships, as parsed layer tuples (data
+    # for the --model reader): (name, type, bottom, top, num_output, pad, kernel,
+    # stride, pool).  Two independent readings must agree: the oracle's protobuf-text parser and
+    # a per-block regular-expression scan.
+    import json
+    import re
+    protos = {}
+    for fn in sorted(os.listdir(REF)):
+        if not fn.endswith('.prototxt'):
+            continue
+        with open(os.path.join(REF, fn)) as f:
+            text = f.read()
+        rows = []
+        for lay in caffe_net.layers_from_prototxt(text):
+            rows.append([lay['name'], lay['type'], lay['bottom'], lay['top'],
+                         lay.get('num_output', 0), lay.get('pad', 0), lay.get('kernel_size', 0),
+                         lay.get('stride', 1 if lay['type'] != 'Pooling' else 0),
+                         lay.get('pool', '') if lay['type'] == 'Pooling' else '',
+                         list(lay.get('shape', ()))])
+        scan = []
+        for block in re.findall(r'layer\s*\{(.*?)\n\}', text, re.S):
+            def grab(key, cast=str, default=None):
+                m = re.search(r'\b%s\s*:\s*"?([\w.]+)"?' % key, block)
+                return cast(m.group(1)) if m else default
+            scan.append([grab('name'), grab('type'), grab('bottom'), grab('top'),
+                         grab('num_output', int, 0), grab('pad', int, 0)])
+        assert [r[:6] for r in rows] == scan, fn
+        protos[fn] = rows
+    out['proto/layers_json'] = np.array(json.dumps(protos, sort_keys=True))
+
     # ------------------------------------------------------------------ 5. parse_args defaults
     sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png']
     args = config_system.parse_args(st.STATE)
