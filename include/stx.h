@@ -246,6 +246,22 @@ int stx_op_pool_forward(stx_engine *e, const float *x, int C, int H, int W, int 
 int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, int H, int W,
                          int mode, const float *relu_mask_data, float *dx);
 
+/* The loss terms of one tapped blob, launched exactly as stx_sc_grad_tile launches them
+ * (style_transfer.py:575-593), for direct comparison with num_utils.gram_matrix / ssymm / norm2 /
+ * normalize (num_utils.py:53-71,85-87,143-147).  All arrays STX_DEVICE.
+ * stx_op_style_terms:   G = tril(F F^T)/(C*h*w);  D = G - gram_target (lower triangle);
+ *                       half_sumsq = 1/2 sum D^2;  s_out = sym(D) F;  abs_sum = sum |s_out|;
+ *                       normalized_out = s_out / (abs_sum/n + EPS)      (either output may be NULL)
+ * stx_op_content_terms: c = F - roll2(content, roll_xy)[:, oy:oy+h, ox:ox+w];
+ *                       sums[0] = sum c^2, sums[1] = sum |c|;  normalized_out = c / (sums[1]/n + EPS)
+ * Both synchronise before returning the host scalars. */
+int stx_op_style_terms(stx_engine *e, const float *feat, int channels, int h, int w,
+                       const float *gram_target, float *s_out, float *normalized_out,
+                       double *half_sumsq, double *abs_sum);
+int stx_op_content_terms(stx_engine *e, const float *feat, int channels, int h, int w,
+                         const float *content, int content_h, int content_w, int oy, int ox,
+                         const int roll_xy[2], float *normalized_out, double sums[2]);
+
 /* Per-kernel-group timing for tuning and for bench.py's roofline figures: while enabled, every
  * launch group of the tile path (one conv / pool / Gram / SYMM / injection) is bracketed by HIP
  * events on the engine stream.  stx_profile_read synchronises, writes one line per group

@@ -72,10 +72,13 @@ class Progress:
 
 
 def image_comment(args, argv):
+    """The PNG iTXt comment (style_transfer.py:1003-1010): command line, then the option and
+    run-state namespaces exactly as the reference prints them (``vars()`` of its lazy namespace,
+    i.e. one ``ns: Namespace(...)`` and one ``state_obj: Namespace(...)`` line)."""
     s = 'Created with style_transfer_amd (CLI-compatible with crowsonkb/style_transfer).\n\n'
     s += 'Command line: style_transfer.py ' + ' '.join(argv) + '\n\nParameters:\n'
-    for key in sorted(args):
-        s += '%s: %s\n' % (key, getattr(args, key))
+    for item in sorted(vars(args).items()):
+        s += '%s: %s\n' % item
     return s
 
 

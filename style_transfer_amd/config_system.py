@@ -107,6 +107,14 @@ def build_parser():
     return parser
 
 
+class ValuePlaceholder:
+    """What a lazy option reads as while the run state it depends on does not exist yet
+    (config_system.py:147-163 of the reference)."""
+
+    def __repr__(self):
+        return 'ValuePlaceholder()'
+
+
 class LazyArgs:
     """Namespace whose callable values are called with the run-state object on every read."""
 
@@ -120,7 +128,7 @@ class LazyArgs:
             try:
                 return value(object.__getattribute__(self, 'state_obj'))
             except AttributeError:
-                return None
+                return ValuePlaceholder()
         return value
 
     def __setattr__(self, name, value):
@@ -148,14 +156,16 @@ def eval_config(path):
 
 
 def parse_args(state=None, argv=None, config_py=None):
-    """Returns the merged options.  ``config_py`` defaults to ``config.py`` beside the CLI."""
+    """Returns the merged options.  ``config_py`` defaults to ``config.py`` beside the entry
+    script of THIS package (the repository's ``style_transfer.py``), like the reference, which
+    looks next to its own config_system.py -- never next to whatever launcher started the process
+    (pytest, torch.distributed.run, ...).  ``config_py=False`` reads no default file."""
     parser = build_parser()
     defaults = vars(parser.parse_args([]))
     given = vars(parser.parse_args(argv))
     merged = dict(defaults)
     if config_py is None:
-        config_py = Path(sys.argv[0]).resolve().parent / 'config.py' if sys.argv and sys.argv[0] \
-            else None
+        config_py = Path(__file__).resolve().parent.parent / 'config.py'
     if config_py and Path(config_py).exists():
         merged.update(eval_config(config_py))
     merged.update({k: v for k, v in given.items() if defaults[k] != v})

@@ -1487,6 +1487,91 @@ int stx_op_pool_backward(stx_engine *e, const float *dy, const float *x, int C, 
     return pool_backward_launch(e->stream, dy, x, C, H, W, mode, relu_mask_data != nullptr, dx);
 }
 
+int stx_op_style_terms(stx_engine *e, const float *feat, int C, int h, int w,
+                       const float *gram_target, float *s_out, float *normalized_out,
+                       double *half_sumsq, double *abs_sum) {
+    if (!e || !feat || !gram_target || C <= 0 || C % 4 || h <= 0 || w <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    const int HW = h * w;
+    const size_t count = (size_t)C * HW;
+    // the launches of the style branch of stx_sc_grad_tile, in the same order
+    const GramPlan plan = gram_plan(C, HW);
+    const size_t fin_blocks = ceil_div(C * C, 64);
+    STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
+    STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
+    STX_TRY(e->upload.ensure(count * sizeof(float)));
+    float *sgrad = s_out ? s_out : e->upload.f();
+    STX_TRY(do_sync(e));
+    size_t si;
+    STX_TRY(alloc_scalars(e, 2, &si));
+    float *sc = e->scalars.f() + si;
+    STX_TRY(gram_partials_launch(e->stream, feat, plan, e->gram_partials.f()));
+    STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr, gram_target,
+                               e->dsym.f(), sc));
+    const ConvConfig cfg = conv_pick_config(1, C, C, h, w);
+    const int n_wg = conv_num_workgroups(cfg, C, h, w);
+    STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+    ConvProblem p{};
+    p.x = feat;
+    p.w = e->dsym.f();
+    p.y = sgrad;
+    p.partials = e->symm_partials.f();
+    p.K = C;
+    p.M = C;
+    p.H = h;
+    p.W = w;
+    p.ksize = 1;
+    p.epilogue = kEpiSymm;
+    STX_TRY(conv_launch(e->stream, cfg, p, false));
+    STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+    if (normalized_out)
+        STX_TRY(inject_style_launch(e->stream, normalized_out, sgrad, count, sc + 1, 1.0f, false));
+    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
+                           hipMemcpyDeviceToHost, e->stream));
+    STX_HIP(hipStreamSynchronize(e->stream));
+    if (half_sumsq) *half_sumsq = 0.5 * (double)e->scalars_host[si];
+    if (abs_sum) *abs_sum = (double)e->scalars_host[si + 1];
+    e->scalars_used = 0;
+    return STX_OK;
+}
+
+int stx_op_content_terms(stx_engine *e, const float *feat, int C, int h, int w,
+                         const float *content, int content_h, int content_w, int oy, int ox,
+                         const int roll_xy[2], float *normalized_out, double sums[2]) {
+    if (!e || !feat || !content || C <= 0 || h <= 0 || w <= 0) return STX_ERR_ARG;
+    if (oy < 0 || ox < 0 || oy + h > content_h || ox + w > content_w) {
+        set_error("stx_op_content_terms: window exceeds the content map");
+        return STX_ERR_ARG;
+    }
+    STX_TRY(e->set_device());
+    ContentWindow win;
+    win.C = C;
+    win.fh = h;
+    win.fw = w;
+    win.ch = content_h;
+    win.cw = content_w;
+    win.oy = oy;
+    win.ox = ox;
+    win.sx = roll_xy ? roll_xy[0] : 0;
+    win.sy = roll_xy ? roll_xy[1] : 0;
+    STX_TRY(do_sync(e));
+    size_t si;
+    STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
+    float *s = e->scalars.f() + si;
+    STX_TRY(content_sums_launch(e->stream, feat, content, win, s));
+    if (normalized_out)
+        STX_TRY(inject_content_launch(e->stream, normalized_out, feat, content, win, s, 1.0f, false));
+    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, (si + 2) * sizeof(float),
+                           hipMemcpyDeviceToHost, e->stream));
+    STX_HIP(hipStreamSynchronize(e->stream));
+    if (sums) {
+        sums[0] = (double)e->scalars_host[si];
+        sums[1] = (double)e->scalars_host[si + 1];
+    }
+    e->scalars_used = 0;
+    return STX_OK;
+}
+
 int stx_profile_enable(stx_engine *e, int on) {
     if (!e) return STX_ERR_ARG;
     STX_TRY(e->set_device());

@@ -109,7 +109,7 @@ class TileEngine:
         self.device = device
         self.handle = None
         descs = (lib.LayerDesc * len(net.layers))()
-        self._strings = []
+        self._names = {}
         for d, lay in zip(descs, net.layers):
             d.name = self._cstr(lay.name)
             d.type = _TYPE_CODES[lay.type]
@@ -129,8 +129,11 @@ class TileEngine:
                 self.set_weights(name, w, b)
 
     def _cstr(self, s):
-        b = s.encode()
-        self._strings.append(b)
+        """Encoded layer name, kept alive for as long as the engine (one entry per distinct
+        name: tap tables are rebuilt on every call)."""
+        b = self._names.get(s)
+        if b is None:
+            b = self._names[s] = s.encode()
         return b
 
     def close(self):

@@ -91,6 +91,8 @@ SIGNATURES = {
     'stx_op_conv_backward_data': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     'stx_op_pool_forward': [_vp, _vp, _i, _i, _i, _i, _vp],
     'stx_op_pool_backward': [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    'stx_op_style_terms': [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, c_double_p, c_double_p],
+    'stx_op_content_terms': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, c_int_p, _vp, c_double_p],
     'stx_last_tile_ms': [_vp, c_float_p],
     'stx_last_tile_flops': [_vp, c_double_p, c_double_p],
     'stx_profile_enable': [_vp, _i],

@@ -84,7 +84,9 @@ class StyleTransfer:
         self.step = 0
         self.step_times = []
         for name in ('swt_weight', 'dd_weight', 'jitter'):
-            if getattr(args, name, 0):
+            # lazy (callable) values could turn non-zero mid-run: refuse them outright
+            raw = getattr(getattr(args, 'ns', args), name, 0)
+            if callable(raw) or raw:
                 raise NotImplementedError('--%s is outside the accelerated path '
                                           '(reference default is off)' % name.replace('_', '-'))
 

@@ -64,3 +64,33 @@ def test_prototxt_round_trip():
 def test_pooled_len_is_caffe_ceil_mode():
     for n in range(1, 70):
         assert netspec.pooled_len(n) == (int(np.ceil((n - 2) / 2)) + 1 if n >= 2 else 1)
+
+
+def _spec_rows(net):
+    """NetSpec -> the tuple layout tests/golden/make_golden.py stores for the reference files."""
+    rows = []
+    for l in net.layers:
+        rows.append([l.name, l.type, l.bottom, l.top, l.num_output if l.type == 'Convolution' else 0,
+                     l.pad if l.type == 'Convolution' else 0,
+                     l.kernel_size if l.type in ('Convolution', 'Pooling') else 0,
+                     l.stride if l.type == 'Pooling' else 1,
+                     l.pool if l.type == 'Pooling' else '',
+                     list(l.shape) if l.type == 'Input' else []])
+    return rows
+
+
+def test_model_reader_reproduces_the_reference_prototxts(golden):
+    """The six deploy files the reference ships (vgg16/vgg19 x {plain, _avgpool, _big}), as
+    parsed layer tuples generated from the reference's own text by make_golden.py: the built-in
+    graphs, and a prototxt written by to_prototxt and read back by parse_prototxt, must both
+    equal them -- including vgg19_big.prototxt:62's rewiring of conv2_1 onto conv1_2."""
+    import json
+    ref = json.loads(str(golden['proto.layers_json']))
+    assert sorted(ref) == ['vgg16.prototxt', 'vgg16_avgpool.prototxt', 'vgg16_big.prototxt',
+                           'vgg19.prototxt', 'vgg19_avgpool.prototxt', 'vgg19_big.prototxt']
+    for fn, rows in ref.items():
+        builtin = netspec.builtin_net(fn)
+        assert _spec_rows(builtin) == rows, fn
+        assert _spec_rows(netspec.parse_prototxt(netspec.to_prototxt(builtin))) == rows, fn
+    big = {r[0]: r for r in ref['vgg19_big.prototxt']}
+    assert big['conv2_1'][2] == 'conv1_2' and big['pool1'][3] == 'pool1'

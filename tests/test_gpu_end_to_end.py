@@ -97,3 +97,35 @@ def test_lbfgs_avgpool_two_styles_matches_reference_run(golden):
     # L-BFGS evaluates the objective once more at the start of every scale (optimizers.py:76-77)
     assert farm.tile_evals == 4 * (3 + 1) + 4 * (2 + 1)
     farm.close()
+
+
+def test_config4_miniature_matches_reference_run(golden):
+    """BASELINE config 4's own combination -- VGG-19 (MAX pooling) x L-BFGS x a 3 x 3 tiling whose
+    last row and column are larger (style_transfer.py:619-632) -- against the reference's run
+    (tests/golden/make_golden.py section 4c): 65 x 71 with 2 x 2 tiles, then 92 x 100 with tiles
+    of 30/30/32 x 33/33/34."""
+    from argparse import Namespace
+    argv = str(golden['e2e_cfg4.argv']).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net(args.model)
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e_cfg4.content_u8'])],
+                           [Image.fromarray(golden['e2e_cfg4.style_u8'])],
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    ref, got = golden['e2e_cfg4.log'], np.float64(log)
+    print(got[:, 2] / ref[:, 2] - 1)
+    assert got.shape == ref.shape
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
+    assert np.allclose(got[:, 3], ref[:, 3], rtol=2e-3)
+    diff = np.abs(st.current_raw.get() - golden['e2e_cfg4.final_raw'])
+    print('final image: max %.4f mean %.6f' % (diff.max(), diff.mean()))
+    assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
+    # 4 tiles x (3 + 1) evaluations at the first scale, 9 tiles x (2 + 1) at the second
+    assert farm.tile_evals == 4 * (3 + 1) + 9 * (2 + 1)
+    farm.close()

@@ -92,3 +92,59 @@ def test_gram_matrix_lower_triangle(c, h, w):
 def test_gram_matches_reference_fixture(golden):
     eng = gpu_engine()
     assert max_rel(eng.gram_matrix(golden['num.feat']), golden['num.gram']) < 2e-5
+
+
+def test_style_terms_match_reference_fixtures(golden):
+    """gram_matrix -> G - Gs -> norm2 -> ssymm -> normalize, launched as the tile path launches
+    them, against the reference's own num_utils results (num_utils.py:53-71,85-87,143-147)."""
+    import ctypes
+    eng = gpu_engine()
+    feat = golden['num.feat']                                  # [64, 17, 23], post-ReLU
+    c, h, w = feat.shape
+    symm_in = golden['num.symm_in']                            # tril(G - Gs) the reference used
+    target = np.tril(golden['num.gram'] - symm_in).astype(np.float32)
+    d_feat, d_tgt = eng.to_device(feat), eng.to_device(target)
+    s_out, norm_out = eng.empty((c, h * w)), eng.empty((c, h * w))
+    half, asum = ctypes.c_double(), ctypes.c_double()
+    lib.call('stx_op_style_terms', eng.handle, d_feat.ptr, c, h, w, d_tgt.ptr, s_out.ptr,
+             norm_out.ptr, ctypes.byref(half), ctypes.byref(asum))
+    assert half.value == pytest.approx(float(golden['num.norm2']), rel=2e-5)      # a8: norm2
+    ref_s = golden['num.symm_out']
+    assert max_rel(s_out.get(), ref_s) < 2e-5                                      # a7: ssymm
+    assert asum.value == pytest.approx(float(np.abs(ref_s).sum(dtype=np.float64)), rel=2e-5)
+    ref_n = num_ops.l1_normalize(ref_s.copy())                                     # a8: normalize
+    assert max_rel(norm_out.get(), ref_n) < 2e-5
+    # oracle on the same inputs (the restatement the other tests lean on)
+    gd = num_ops.gram_lower(feat) - target
+    assert max_rel(s_out.get(), num_ops.symm_lower_times(gd, feat.reshape(c, -1))) < 2e-5
+
+
+def test_content_terms_match_reference_normalize(golden):
+    """F - Fc window sums and the normalized residual; with Fc = 0 this is num_utils.normalize /
+    norm2 / sasum on the fixture itself (num_utils.py:69-71,85-87)."""
+    import ctypes
+    eng = gpu_engine()
+    feat = golden['num.feat']
+    c, h, w = feat.shape
+    d_feat = eng.to_device(feat)
+    zeros = eng.empty((c, h + 3, w + 5)).zero()
+    out = eng.empty(feat.shape)
+    sums = (ctypes.c_double * 2)()
+    roll = (ctypes.c_int * 2)(0, 0)
+    lib.call('stx_op_content_terms', eng.handle, d_feat.ptr, c, h, w, zeros.ptr, h + 3, w + 5, 2,
+             4, roll, out.ptr, sums)
+    assert max_rel(out.get(), golden['num.normalize']) < 1e-5
+    assert sums[0] / 2 == pytest.approx(num_ops.half_sq_norm(feat), rel=1e-5)
+    assert sums[1] == pytest.approx(float(np.abs(feat).sum(dtype=np.float64)), rel=1e-5)
+    # a rolled window of a real content map against the oracle's slicing of the rolled copy
+    rng = np.random.RandomState(4)
+    content = rng.standard_normal((c, 31, 40)).astype(np.float32)
+    d_content = eng.to_device(content)
+    roll_xy = (-7, 12)
+    roll = (ctypes.c_int * 2)(*roll_xy)
+    lib.call('stx_op_content_terms', eng.handle, d_feat.ptr, c, h, w, d_content.ptr, 31, 40, 9, 6,
+             roll, out.ptr, sums)
+    rolled = num_ops.roll_xy(content.copy(), roll_xy)
+    resid = feat - rolled[:, 9:9 + h, 6:6 + w]
+    assert sums[0] / 2 == pytest.approx(num_ops.half_sq_norm(resid), rel=1e-5)
+    assert max_rel(out.get(), num_ops.l1_normalize(resid.copy())) < 1e-5
