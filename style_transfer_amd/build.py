@@ -22,6 +22,7 @@ SOURCES = {
     'conv_mfma.hip': [],
     'conv_wino.hip': [],
     'conv_wino2.hip': [],
+    'conv_wino4.hip': [],
     'gram.hip': [],
     'pool.hip': [],
     'reduce.hip': [],

@@ -160,6 +160,11 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
 bool wino2_fuses_pool(const ConvProblem &p);
 int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 
+// Four-wave form of the same kernel (conv_wino4.hip); config ids 210 (4 x 64 pixel patches),
+// 211 (16 x 16), 212 (8 x 32).  Shares the packed bank, the pooling rule and the K-split model.
+ConvConfig wino4_config(int geometry = 0);
+int wino4_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);
 int conv_small_pack(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,

@@ -321,6 +321,7 @@ static const WinoVariant kWino[] = {
 };
 
 ConvConfig wino_config_by_id(int id) {
+    if (id >= 110) return wino4_config(id - 110);
     if (id >= 100) return wino2_config(id - 100);
     const WinoVariant &v = kWino[id];
     ConvConfig c;

@@ -692,6 +692,7 @@ static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
 }
 
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    if (cfg.id >= 210) return wino4_launch(s, cfg, p, ksplit);
     WinoArgs a;
     a.x = p.x;
     a.w = p.w;

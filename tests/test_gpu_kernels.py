@@ -20,7 +20,7 @@ CONV_CASES = [  # (Cin, Cout, H, W): SURVEY section 8c list + shapes that hit ev
     (512, 512, 16, 16), (64, 3, 37, 50), (128, 64, 24, 72), (20, 36, 19, 31), (16, 70, 13, 200),
     (72, 40, 130, 129)]
 # every convolution kernel family on every shape it accepts; None = the engine's own choice
-CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b']
+CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino4a', 'wino4b', 'wino4c']
 
 
 @pytest.mark.parametrize('algo', CONV_ALGOS)

@@ -10,7 +10,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ long long g_t[4];
 
-enum { kNone, kAdd, kPkAdd, kDsWrite128, kDsRead128, kBufLoad128, kMix };
+enum { kNone, kAdd, kPkAdd, kDsWrite128, kDsRead128, kBufLoad128, kMix, kBurstPk, kBurstAdd, kBurstPkDep };
 
 template <int MODE, int F>
 __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters, float a, float b) {
@@ -45,8 +45,18 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
                     f32x4 t = l4[(j & 7) * 256 + wave * 64 + (lane & 31)];
                     asm volatile("" :: "v"(t));       // discarded: only the issue matters
                 }
+                if (MODE >= kBurstPk) continue;
                 if (MODE == kBufLoad128)
                     ld[j & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(threadIdx.x * 16u), (unsigned)((j & 15) * 4096), 0);
+            }
+            // one burst of F vector instructions per 16 MFMAs
+            if (MODE >= kBurstPk && i == 7) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    if (MODE == kBurstPk) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[f & 7]) : "v"(v[(f + 1) & 7]));
+                    if (MODE == kBurstAdd) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[f & 7].x) : "v"(v[(f + 1) & 7].y));
+                    if (MODE == kBurstPkDep) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v[(f + 3) & 7]) : "v"(v[f & 7]), "v"(v[(f + 1) & 7]));
+                }
             }
         }
     }
@@ -73,8 +83,8 @@ template <int MODE, int F> void run(const char *name) {
     hipDeviceSynchronize();
     long long t[4];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(g_t), sizeof(t));
-    printf("%-22s x%d per MFMA: %6.1f cycles per MFMA (waves %lld %lld %lld %lld)\n", name, F,
-           (double)t[0] / (iters * 16.0), t[0], t[1], t[2], t[3]);
+    printf("%-22s x%d per MFMA: %6.1f cycles per MFMA, %7.1f per 16 MFMAs (waves %lld %lld %lld %lld)\n", name, F,
+           (double)t[0] / (iters * 16.0), (double)t[0] / iters, t[0], t[1], t[2], t[3]);
     hipFree(out), hipFree(in);
 }
 
@@ -200,6 +210,13 @@ int main() {
     run<kDsRead128, 2>("ds_read_b128");
     run<kBufLoad128, 1>("buffer_load_b128");
     run<kBufLoad128, 2>("buffer_load_b128");
+    run<kBurstPk, 4>("burst pk /16 MFMA");
+    run<kBurstPk, 8>("burst pk /16 MFMA");
+    run<kBurstPk, 16>("burst pk /16 MFMA");
+    run<kBurstPk, 32>("burst pk /16 MFMA");
+    run<kBurstAdd, 16>("burst add /16 MFMA");
+    run<kBurstAdd, 32>("burst add /16 MFMA");
+    run<kBurstPkDep, 16>("burst pk mods /16 MFMA");
     run_chunk<0>("chunk skeleton, plain adds");
     run_chunk<1>("chunk skeleton, pk adds");
     run_chunk<2>("chunk skeleton, no VALU");

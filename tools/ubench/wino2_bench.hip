@@ -1,6 +1,7 @@
 // Standalone timing harness for conv_wino2.hip (tuning aid, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I style_transfer_amd/csrc \
-//         [-DSTX_WINO2_TIMING] tools/ubench/wino2_bench.hip -o /tmp/wino2_bench
+//         [-DSTX_WINO2_TIMING] tools/ubench/wino2_bench.hip style_transfer_amd/csrc/conv_wino4.hip \
+//         -o /tmp/wino2_bench
 // With STX_WINO2_TIMING the kernel accumulates, per wave of workgroup 0, the core-clock cycles
 // spent in its compute segments, hand-over segments and barrier waits; the harness prints them.
 #include "../../style_transfer_amd/csrc/conv_wino2.hip"
@@ -8,6 +9,9 @@
 #include <vector>
 
 namespace stx {
+#ifdef STX_WINO4_TIMING
+extern __device__ long long g_wino4_timing[4][4];
+#endif
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -34,7 +38,9 @@ static void run(int K, int M, int H, int W, int epilogue) {
     ConvProblem p{};
     p.x = x, p.w = w, p.y = y, p.bias = nullptr, p.mask = epilogue == kEpiDgrad ? mask : nullptr;
     p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = 1, p.epilogue = epilogue;
-    const ConvConfig cfg = wino2_config(getenv("GEO") ? atoi(getenv("GEO")) : wino2_pick_geometry(H, W));
+    const int geo = getenv("GEO") ? atoi(getenv("GEO")) : wino2_pick_geometry(H, W);
+    // ALGO=4: the four-wave kernel (conv_wino4.hip, linked as its own translation unit)
+    const ConvConfig cfg = getenv("ALGO") && atoi(getenv("ALGO")) == 4 ? wino4_config(geo) : wino2_config(geo);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) wino2_launch(0, cfg, p, 1);
@@ -49,6 +55,15 @@ static void run(int K, int M, int H, int W, int epilogue) {
     const double flop = 2.0 * M * K * 9 * H * W;
     printf("K %4d M %4d %4dx%-4d epi %d: %.3f ms  %.1f TFLOP/s (direct-equivalent)  %.1f%% of MFMA time\n",
            K, M, H, W, epilogue, ms, flop / ms / 1e9, 100.0 * (flop * 16 / 36 / 157.3e12) / (ms * 1e-3));
+#ifdef STX_WINO4_TIMING
+    if (cfg.id >= 210) {
+        long long t4[4][4];
+        hipMemcpyFromSymbol(t4, HIP_SYMBOL(stx::g_wino4_timing), sizeof(t4));
+        for (int wv = 0; wv < 4; wv += 3)
+            printf("   wave %d: prologue %6lld  chunk loop %7lld (%.0f per chunk)  epilogue %6lld cycles\n", wv,
+                   t4[wv][0], t4[wv][1], (double)t4[wv][1] / ((K + 7) / 8), t4[wv][2]);
+    }
+#endif
 #ifdef STX_WINO2_TIMING
     long long t[8][8];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
@@ -61,6 +76,7 @@ static void run(int K, int M, int H, int W, int epilogue) {
 }
 
 int main() {
+    run(512, 512, 64, 64, stx::kEpiForward);
     run(512, 512, 128, 128, stx::kEpiForward);
     run(256, 256, 256, 256, stx::kEpiForward);
     run(128, 128, 512, 512, stx::kEpiForward);
