@@ -20,12 +20,20 @@ transfers over RCCL, there is no collective on the data path.  value = tile-iter
 of the whole job.
 
 The line also carries
-  roofline      algorithmic FLOP of the four tile-iterations of one GPU (SURVEY.md section 8d:
-                1 514 240 FLOP per tile pixel) over the GPU time of that concurrent group of
-                stx_sc_grad_tile calls -- HIP events on each engine's own stream inside the timed
-                region, the longest of the four spans -- against the fp32 MFMA peak;
+  roofline      the matrix-core work the kernels ISSUE for the four tile-iterations of one GPU
+                (convolutions through Winograd F(2x2,3x3) issue 4/9 of a direct convolution's
+                MFMAs; Gram and SYMM products in full) over the GPU time of that concurrent group
+                of stx_sc_grad_tile calls -- HIP events on each engine's own stream inside the
+                timed region, the longest of the four spans -- against the fp32 MFMA peak, so that
+                frac <= 1 by construction; `bound_ms` is the time the same work takes at that
+                peak.  The SURVEY 8d figure (1 514 240 FLOP per tile pixel, every convolution
+                counted as a direct one) is kept beside it as achieved_direct_equiv;
+  steady        the same step loop run for at least 5 s after the timed region;
+  wall_clock_s  the WHOLE `--size 2048 --tile-size 1024` command-line run (7 pyramid scales,
+                800 iterations, 1400 tile-iterations, preprocessing and PNG output included) on
+                synthetic pictures, on this job's GPUs through one host process (TileFarm);
   cpu_baseline  the numpy oracle (a port of the reference's Caffe-CPU path) timed on this box's
-                host cores on a bounded sample -- rank 0, N = 1 only.
+                host cores on one 1024 x 1024 tile-iteration -- rank 0, N = 1 only.
 """
 
 import argparse
@@ -59,24 +67,28 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
+TRAFFIC_PROFILE = 'profiles/r02_hbm_traffic_pmc.json'
+
+
 def measured_traffic():
-    """HBM bytes per stx_sc_grad_tile launch from the PMC passes of this build
-    (profiles/r01_i_hbm_traffic_pmc.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-    separate runs of this script, FETCH_SIZE doubled per the gfx950 calibration on the Adam
-    kernel -- tools/pmc_traffic.py).  None if the file is missing."""
-    path = os.path.join(REPO, 'profiles', 'r01_i_hbm_traffic_pmc.json')
+    """(bytes per launch group, source file): HBM bytes from the PMC passes over THIS script
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per
+    the gfx950 calibration on the Adam kernel -- tools/pmc_traffic.py).  Counters cannot be
+    collected inside a timed run, so the figure is a replay of the committed profile of this
+    build state and the line names the file; (None, None) if it is missing."""
     try:
-        with open(path) as f:       # measured per tile-iteration; one launch group = 4 of them
-            return float(json.load(f)['hbm_bytes_per_tile_iteration']) * TILES_PER_GPU
+        with open(os.path.join(REPO, TRAFFIC_PROFILE)) as f:
+            # measured per tile-iteration; one launch group = 4 of them
+            return float(json.load(f)['hbm_bytes_per_tile_iteration']) * TILES_PER_GPU, TRAFFIC_PROFILE
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(net):
     """Times the oracle's tile evaluation on the host cores (checker used as a yardstick only)."""
     from oracle.caffe_net import synthetic_weights
     from oracle.tile_path import OracleModel
-    size = 512
+    size = TILE
     layers = net.as_dicts()
     om = OracleModel(layers, synthetic_weights(layers, 0))
     rng = np.random.RandomState(1)
@@ -88,16 +100,57 @@ def cpu_baseline(net):
                   for l in STYLE_LAYERS}]
     om.sc_grad_tile(tile[:, :128, :128], (0, 0), CONTENT_LAYERS, STYLE_LAYERS, {}, cw, sw)  # warm
     reps, t0 = 0, time.perf_counter()
-    while reps < 2 or (time.perf_counter() - t0 < 10 and reps < 8):
+    while reps < 1 or (time.perf_counter() - t0 < 12 and reps < 3):
         om.sc_grad_tile(tile, (0, 0), CONTENT_LAYERS, STYLE_LAYERS, {}, cw, sw)
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    return {'value': 1.0 / (dt * (TILE * TILE) / (size * size)), 'unit': 'tile-iterations/s',
-            'cores': cores, 'kind': 'port',
-            'sample': '%d VGG-19 tile-iterations at %dx%d with the numpy oracle (im2col + '
-                      'multithreaded SGEMM, %.2f s each), scaled by pixel count to the '
-                      '%dx%d benchmark tile' % (reps, size, size, dt, TILE, TILE)}
+    return {'value': 1.0 / dt, 'unit': 'tile-iterations/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d VGG-19 tile-iteration(s) at the benchmark tile size %dx%d with the numpy '
+                      'oracle (im2col + multithreaded SGEMM, %.2f s each), no scaling'
+                      % (reps, size, size, dt)}
+
+
+def whole_run_wall_clock(devices):
+    """Wall-clock of the reference's command line for the metric's configuration, start to finish:
+    `--size 2048 --tile-size 1024`, Adam, default iterations (200 + 6 x 100 over 7 scales = 1400
+    tile-iterations), synthetic 2048 x 2048 pictures, seeded synthetic weights, ONE host process
+    driving `devices` through TileFarm.  Runs as a child process (a failure there cannot take the
+    benchmark line with it).  wall_clock_s is what the command itself reports in its last line,
+    like the reference (style_transfer.py:1152-1163); process_wall_s includes interpreter and HIP
+    start-up."""
+    import re
+    import subprocess
+    import tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix='stx_bench_')
+
+    def picture(seed, name):
+        r = np.random.RandomState(seed)
+        small = r.uniform(0, 255, (128, 128, 3)).astype(np.uint8)
+        big = np.asarray(Image.fromarray(small).resize((2048, 2048), Image.BICUBIC), np.float32)
+        Image.fromarray(np.uint8(np.clip(big + r.uniform(-16, 16, big.shape), 0, 255))).save(
+            os.path.join(tmp, name))
+    picture(0, 'content.png')
+    picture(1, 'style.png')
+    args = ['-ci', 'content.png', '-si', 'style.png', '--size', '2048', '--tile-size', '1024',
+            '--weights', 'synthetic', '--display', 'none', '-oi', 'out.png',
+            '--devices'] + [str(d) for d in devices]
+    t0 = time.perf_counter()
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'style_transfer.py')] + args, cwd=tmp,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    outer = time.perf_counter() - t0
+    lines = proc.stdout.splitlines()
+    if proc.returncode != 0:
+        raise RuntimeError('style_transfer.py exited with %d: %s' % (proc.returncode,
+                                                                     ' | '.join(lines[-3:])))
+    m = re.search(r'ending after (\d+)m ([\d.]+)s', proc.stdout)
+    wall = int(m.group(1)) * 60 + float(m.group(2)) if m else outer
+    summary = [l for l in lines if 'tile-iterations in' in l or 'ending after' in l]
+    return {'wall_clock_s': wall, 'process_wall_s': outer,
+            'wall_clock_command': 'style_transfer.py ' + ' '.join(args),
+            'wall_clock_steps': sum(1 for l in lines if l.startswith('Step ')),
+            'wall_clock_summary': summary}
 
 
 def main():
@@ -106,6 +159,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-wall-clock', action='store_true',
+                    help='skip the whole-run wall-clock leg (about 10 s)')
+    ap.add_argument('--steady-seconds', type=float, default=5.0)
     opts = ap.parse_args()
 
     import torch                                       # first: one HIP runtime for both libraries
@@ -141,7 +197,12 @@ def main():
     from style_transfer_amd.weights import synthetic_weights
 
     net = builtin_net('vgg19')
-    weights = synthetic_weights(net, 0)
+    # weights: built once on rank 0 and broadcast with ONE RCCL collective (80 MB); every other
+    # rank sets its engines from the received device tensors
+    weights = synthetic_weights(net, 0) if rank == 0 else None
+    if world > 1:
+        from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
+        weights = broadcast_weights(weights, device)
     # every rank: TILES_PER_GPU engines (HIP streams) on its GPU, one tile of the step each
     engines = [TileEngine(net, local_rank, weights) for _ in range(TILES_PER_GPU)]
     eng = engines[0]
@@ -152,28 +213,25 @@ def main():
     content_weight = {'conv4_2': 0.05}
     style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
 
-    # ---- targets (once, outside the timed region): style Grams and the content map of the image
+    # ---- targets (once, outside the timed region): style Grams and the content map of the
+    # image, computed on rank 0's GPU and broadcast device to device
     contents, styles = [], []
     if rank == 0:
         helper = TileFarm(net, verbose=False, engines=[eng])
         style_feats = helper.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS,
                                                      TILE, passes=1)
         styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
-        contents = [{l: f.get() for l, f in helper.prepare_features_device(
-            smooth_picture(8, H, W), CONTENT_LAYERS, TILE, passes=1).items()}]
+        contents = [helper.prepare_features_device(smooth_picture(8, H, W), CONTENT_LAYERS, TILE,
+                                                   passes=1)]
     if world > 1:
-        from style_transfer_amd.dist import DistributedTiles, broadcast_targets
         contents, styles = broadcast_targets(contents, styles, device)
     for e in engines:
         e.set_contents_and_styles(contents, styles)
+        e.sync()
 
     def wrap(tensor, engine):
         """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
-        arr = DeviceArray.__new__(DeviceArray)
-        arr.engine, arr.shape, arr.dtype = engine, tuple(tensor.shape), np.dtype(np.float32)
-        arr.nbytes, arr.ptr = tensor.numel() * 4, tensor.data_ptr()
-        arr.free = lambda: None
-        return arr
+        return DeviceArray.from_pointer(engine, tensor.data_ptr(), tensor.shape, owner=tensor)
 
     group_ms = []           # GPU time of one concurrent group of tile evaluations on this rank
     state = {}
@@ -280,18 +338,38 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if debug_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    timed_group_ms = list(group_ms)
+
+    # ---- a second, longer measurement of the same loop (the timed region above is short)
+    steady = None
+    if opts.steady_seconds > 0:
+        n_steady = max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))
+        if world > 1:
+            t = torch.tensor([n_steady], dtype=torch.int64, device='cpu' if debug_one_gpu else device)
+            dist.broadcast(t, 0)
+            n_steady = int(t[0])
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_steady):
+            step()
+        fence()
+        dt = time.perf_counter() - t1
+        steady = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
+                  'value': len(rects) * n_steady / dt, 'unit': 'tile-iterations/s'}
 
     if rank == 0:
         ms_per_step = elapsed / opts.steps * 1e3
         tiles_per_step = len(rects)
-        avg_group_ms = float(np.mean(group_ms))
+        avg_group_ms = float(np.mean(timed_group_ms))
         flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
-        achieved = flop / (avg_group_ms * 1e-3) / 1e12
+        direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
         # what the kernels actually put on the matrix cores: the 3x3 layers run Winograd kernels
-        # that issue 4/9 (2-D) or 2/3 (1-D) of the direct-convolution MFMAs
+        # that issue 4/9 (2-D) or 2/3 (1-D) of the direct-convolution MFMAs; Gram / SYMM in full
         conv_alg, conv_issued = eng.last_tile_flops()
         issued = (flop / TILES_PER_GPU - conv_alg + conv_issued) * TILES_PER_GPU
         issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
+        bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+        traffic, traffic_src = measured_traffic()
         line = {
             'metric': 'tile-iterations/sec, VGG-19 2048px/1024-tile (fwd+bwd, Gram/content losses, '
                       'regularizers, Adam step)',
@@ -306,20 +384,38 @@ def main():
                        'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
                        'tiles_per_step': tiles_per_step, 'tiles_per_gpu': TILES_PER_GPU,
                        'final_loss': loss},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                         'traffic': measured_traffic(), 'traffic_unit': 'bytes per launch',
-                         'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU (conv_wino2_kernel '
-                                   'fwd/dgrad, conv_mfma_kernel first layer + SYMM, gram)' % TILES_PER_GPU,
-                         'flop_per_launch': flop, 'avg_launch_ms': avg_group_ms,
-                         'mfma_issued': issued_tflops,
-                         'mfma_issued_frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
-                         'note': 'achieved / frac count every convolution as a direct one (SURVEY 8d: '
-                                 '1 514 240 FLOP per tile pixel); the 3x3 layers run Winograd '
-                                 'F(2x2,3x3) kernels that issue 4/9 of those MFMAs, so frac can exceed '
-                                 '1 -- mfma_issued(_frac) is the matrix-core work actually issued, '
-                                 'against the same fp32 MFMA peak'},
+            'roofline': {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
+                         'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / TILES_PER_GPU,
+                         'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                         'traffic_source': traffic_src,
+                         'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU (conv_wino4_kernel / '
+                                   'conv_wino2_kernel fwd + dgrad, conv_mfma_kernel first layer + '
+                                   'SYMM, gram)' % TILES_PER_GPU,
+                         'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
+                         'achieved_direct_equiv': direct_equiv,
+                         'flop_direct_equiv_per_launch': flop,
+                         'note': 'achieved / frac = matrix-core FLOP actually issued (Winograd '
+                                 'F(2x2,3x3) convolutions issue 4/9 of a direct convolution, Gram '
+                                 'and SYMM in full) over the HIP-event time of the launch group, '
+                                 'against the fp32 MFMA peak at 2.4 GHz; achieved_direct_equiv '
+                                 'credits every convolution as a direct one (SURVEY 8d: 1 514 240 '
+                                 'FLOP per tile pixel) and is not a roofline fraction; traffic is '
+                                 'a replay of the committed PMC profile named in traffic_source, '
+                                 'not a measurement of this run'},
         }
+        if steady is not None:
+            line['steady'] = steady
+        if not opts.no_wall_clock and not debug_one_gpu:
+            # the whole command-line run on this job's GPUs, one host process (the other ranks
+            # wait at the barrier below)
+            for e in engines:
+                e.sync()
+            try:
+                line.update(whole_run_wall_clock(list(range(world))))
+            except Exception as err:      # pylint: disable=broad-except
+                line['wall_clock_s'] = None
+                line['wall_clock_error'] = '%s: %s' % (type(err).__name__, err)
         if world == 1 and not opts.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(net)
         print(json.dumps(line), flush=True)

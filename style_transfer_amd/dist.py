@@ -16,9 +16,13 @@ worker.  Per evaluation:
 Tiles never exchange data with each other, so there is no collective on the data path: the
 scatter and the gather are batched point-to-point transfers (``batch_isend_irecv``), which on
 RCCL run concurrently over the separate xGMI links from GPU 0 to each peer -- 12 bytes per tile
-pixel each way.  Targets (style Grams, content maps) are broadcast once per scale with
-``broadcast_targets``.  The arithmetic is injected through callables so that the protocol can
-be exercised on CPU (gloo) in the unit tests.
+pixel each way.  The iteration's shift (``roll``) travels in the same batch as the tiles, as a
+two-element message to each peer (the reference puts it into every SCGradRequest,
+``style_transfer.py:158-161,634-637``).  Collectives run once, outside the step loop:
+``broadcast_weights`` (the VGG filter bank, once per run) and ``broadcast_targets`` (style Grams
+and content maps, once per scale); both hand back tensors on the compute device, nothing is
+bounced through host memory.  The arithmetic is injected through callables so that the protocol
+can be exercised on CPU (gloo) in the unit tests.
 """
 
 import numpy as np
@@ -79,11 +83,6 @@ class DistributedTiles:
     def eval_sc_grad(self, rects, roll):
         """rects: the tile grid [(y0,y1,x0,x1)] (identical on all ranks); roll: (x, y) pixel
         shift, significant on rank 0.  Returns the summed loss on rank 0 (None elsewhere)."""
-        header = torch.zeros(2, dtype=torch.int64, device=self.wire)
-        if self.rank == 0:
-            header[0], header[1] = int(roll[0]), int(roll[1])
-        dist.broadcast(header, 0, group=self.group)
-        roll = (int(header[0]), int(header[1]))
         owner = [t % self.world for t in range(len(rects))]
         mine = [t for t in range(len(rects)) if owner[t] == self.rank]
         shape = lambda t: (3, rects[t][1] - rects[t][0], rects[t][3] - rects[t][2])
@@ -92,7 +91,12 @@ class DistributedTiles:
         tiles = {}
         ops = []
         if self.rank == 0:
+            roll = (int(roll[0]), int(roll[1]))
             own = [t for t in range(len(rects)) if owner[t] == 0]
+            # the shift goes to every peer that has work, in the same batch as its tiles
+            header = torch.tensor(roll, dtype=torch.int64, device=self.wire)
+            for r in sorted(set(owner) - {0}):
+                ops.append(dist.P2POp(dist.isend, header, r, self.group))
             # peers' tiles first, so that they leave while this rank cuts and starts its own
             for t, rect in enumerate(rects):
                 if owner[t] != 0:
@@ -117,10 +121,16 @@ class DistributedTiles:
                 self._sync()
                 results = self.evaluate(jobs, roll) if jobs else []
         else:
+            header = self._buffer('roll', (2,), torch.int64)
+            if mine:
+                ops.append(dist.P2POp(dist.irecv, header, 0, self.group))
             for t in mine:
                 tiles[t] = self._buffer(('tile', t), shape(t))
                 ops.append(dist.P2POp(dist.irecv, tiles[t], 0, self.group))
             self._run(ops)
+            if mine:
+                hdr = header.cpu()
+                roll = (int(hdr[0]), int(hdr[1]))
             tiles = {t: self._in(buf) for t, buf in tiles.items()}
             self._sync()
             # ---- evaluate the local tiles (possibly concurrently, that is the callee's business)
@@ -165,11 +175,48 @@ class DistributedTiles:
         return None
 
 
-def broadcast_targets(contents, styles, device, group=None):
-    """Broadcasts rank 0's targets (lists of {layer: ndarray}) to every rank."""
-    rank = dist.get_rank(group)
+def _wire_device(device, group):
     if torch.device(device).type == 'cuda' and dist.get_backend(group) == 'gloo':
-        device = 'cpu'                      # host-staged debug path, see DistributedTiles
+        return torch.device('cpu')          # host-staged debug path, see DistributedTiles
+    return torch.device(device)
+
+
+def broadcast_weights(weights, device, group=None):
+    """Rank 0's filter bank {conv layer: (w [Cout,Cin,k,k], b [Cout])} to every rank: ONE RCCL
+    broadcast of the packed bank (80 MB for VGG-19), once per run (the reference makes every
+    worker process read the .caffemodel itself, style_transfer.py:187-207).  Returns
+    {layer: (w, b)} as views of one flat tensor on ``device``; keep the dict alive while engines
+    copy from it."""
+    rank = dist.get_rank(group)
+    wire = _wire_device(device, group)
+    meta = [None]
+    if rank == 0:
+        meta[0] = [(name, tuple(w.shape), tuple(b.shape)) for name, (w, b) in weights.items()]
+    dist.broadcast_object_list(meta, 0, group=group)
+    total = sum(int(np.prod(ws)) + int(np.prod(bs)) for _, ws, bs in meta[0])
+    if rank == 0:
+        flat = torch.from_numpy(np.concatenate(
+            [np.concatenate([np.ravel(np.asarray(weights[name][0], np.float32)),
+                             np.ravel(np.asarray(weights[name][1], np.float32))])
+             for name, _, _ in meta[0]])).to(wire)
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=wire)
+    dist.broadcast(flat, 0, group=group)
+    flat = flat.to(torch.device(device))
+    out, pos = {}, 0
+    for name, ws, bs in meta[0]:
+        nw, nb = int(np.prod(ws)), int(np.prod(bs))
+        out[name] = (flat[pos:pos + nw].view(ws), flat[pos + nw:pos + nw + nb].view(bs))
+        pos += nw + nb
+    return out
+
+
+def broadcast_targets(contents, styles, device, group=None):
+    """Broadcasts rank 0's targets (lists of {layer: array}) to every rank, once per scale.
+    Sources may be numpy arrays, torch tensors or anything with ``.get()`` (DeviceArray); the
+    result is lists of {layer: torch tensor on ``device``} -- the maps stay on the GPU."""
+    rank = dist.get_rank(group)
+    wire = _wire_device(device, group)
     meta = [None]
     if rank == 0:
         meta[0] = ([{k: tuple(v.shape) for k, v in c.items()} for c in contents],
@@ -183,13 +230,16 @@ def broadcast_targets(contents, styles, device, group=None):
             d = {}
             for layer, shape in shape_map.items():
                 if rank == 0:
-                    host = src[i][layer]
-                    host = host.get() if hasattr(host, 'get') else host
-                    t = torch.from_numpy(np.ascontiguousarray(host, np.float32)).to(device)
+                    v = src[i][layer]
+                    if isinstance(v, torch.Tensor):
+                        t = v.to(wire, torch.float32).contiguous()
+                    else:
+                        v = v.get() if hasattr(v, 'get') else v
+                        t = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(wire)
                 else:
-                    t = torch.empty(shape, dtype=torch.float32, device=device)
+                    t = torch.empty(shape, dtype=torch.float32, device=wire)
                 dist.broadcast(t, 0, group=group)
-                d[layer] = t.cpu().numpy()
+                d[layer] = t.to(torch.device(device))
             items.append(d)
         out.append(items)
     return out[0], out[1]

@@ -38,6 +38,17 @@ class DeviceArray:
         lib.call('stx_malloc', engine.handle, self.nbytes, ctypes.byref(ptr))
         self.ptr = ptr.value
 
+    @classmethod
+    def from_pointer(cls, engine, ptr, shape, dtype=np.float32, owner=None):
+        """A view of device memory somebody else owns (e.g. a torch tensor: pass it as ``owner``
+        to keep it alive).  ``free()`` does nothing."""
+        arr = cls.__new__(cls)
+        arr.engine, arr.shape, arr.dtype = engine, tuple(int(v) for v in shape), np.dtype(dtype)
+        arr.nbytes = int(np.prod(arr.shape, dtype=np.int64)) * arr.dtype.itemsize
+        arr.ptr, arr.owner = int(ptr), owner
+        arr.free = lambda: None
+        return arr
+
     @property
     def size(self):
         return int(np.prod(self.shape, dtype=np.int64))
@@ -80,9 +91,15 @@ class DeviceArray:
 
 
 def _as_arg(arr):
-    """(pointer, mem tag, keep-alive object) for a numpy array or DeviceArray."""
+    """(pointer, mem tag, keep-alive object) for a numpy array, a DeviceArray or a float32 torch
+    tensor (on a GPU: used in place; on the CPU: its memory is the host buffer)."""
     if isinstance(arr, DeviceArray):
         return arr.ptr, lib.DEVICE, arr
+    if hasattr(arr, 'data_ptr') and hasattr(arr, 'is_cuda'):        # torch.Tensor, no import
+        t = arr.contiguous()
+        if str(t.dtype) != 'torch.float32':
+            t = t.float()
+        return t.data_ptr(), (lib.DEVICE if t.is_cuda else lib.HOST), t
     host = np.ascontiguousarray(arr, np.float32)
     return host.ctypes.data, lib.HOST, host
 
@@ -173,10 +190,16 @@ class TileEngine:
         return ch, h, w
 
     def set_weights(self, conv_layer, w, b):
-        w = np.ascontiguousarray(w, np.float32)
-        b = np.ascontiguousarray(b, np.float32)
-        lib.call('stx_set_conv_weights', self.handle, conv_layer.encode(), w.ctypes.data,
-                 b.ctypes.data, lib.HOST)
+        """w [Cout,Cin,k,k], b [Cout]: numpy, DeviceArray or torch tensors (device-resident
+        sources are copied on the engine's stream, e.g. straight out of an RCCL broadcast)."""
+        wp, wmem, wkeep = _as_arg(w)
+        bp, bmem, bkeep = _as_arg(b)
+        if wmem != bmem:
+            raise ValueError('weights and bias must live on the same side')
+        lib.call('stx_set_conv_weights', self.handle, conv_layer.encode(), wp, bp, wmem)
+        if wmem == lib.DEVICE:
+            self.sync()          # the sources may be released once this returns
+        del wkeep, bkeep
 
     # ------------------------------------------------------------- SetContentsAndStyles
     def set_contents_and_styles(self, contents, styles):

@@ -32,7 +32,7 @@ def _problem():
 
 
 def _worker(rank, world, port, out_path, two_phase=False):
-    from style_transfer_amd.dist import DistributedTiles, broadcast_targets
+    from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -43,7 +43,12 @@ def _worker(rank, world, port, out_path, two_phase=False):
         styles = [om.style_grams([style], sl, 512)]
         contents = [om.prepare_features(img, cl, 512)]
     contents, styles = broadcast_targets(contents, styles, 'cpu')
-    om.contents, om.styles = contents, styles
+    om.contents = [{k: v.numpy() for k, v in c.items()} for c in contents]
+    om.styles = [{k: v.numpy() for k, v in s_.items()} for s_ in styles]
+    # the filter bank travels once, as one broadcast: rank 1 starts without it
+    bank = broadcast_weights(om.net.params if rank == 0 else None, 'cpu')
+    for name, (w, b) in make_oracle('vgg16_avgpool')[0].net.params.items():
+        assert np.array_equal(bank[name][0].numpy(), w) and np.array_equal(bank[name][1].numpy(), b)
     roll = (16, -8)
     rolled = roll_xy(img.copy(), roll)
     grad = np.zeros_like(img)
@@ -73,7 +78,8 @@ def _worker(rank, world, port, out_path, two_phase=False):
 
     farm = DistributedTiles(cut, (begin, end) if two_phase else evaluate, put, 'cpu')
     rects = tile_grid(img.shape[-2:], 32)
-    loss = farm.eval_sc_grad(rects, roll if rank == 0 else (0, 0))
+    # only rank 0 knows the shift; it reaches rank 1 with the tiles, not through a collective
+    loss = farm.eval_sc_grad(rects, roll if rank == 0 else None)
     if rank == 0:
         np.savez(out_path, loss=loss, grad=grad, n_tiles=len(rects))
     dist.barrier()
