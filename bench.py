@@ -162,6 +162,9 @@ def main():
     ap.add_argument('--no-wall-clock', action='store_true',
                     help='skip the whole-run wall-clock leg (about 10 s)')
     ap.add_argument('--steady-seconds', type=float, default=5.0)
+    ap.add_argument('--debug-grid', default=None,
+                    help='RxC tile grid instead of the one for --gpus (tests only: lets a single '
+                         'process evaluate the image of a larger job)')
     opts = ap.parse_args()
 
     import torch                                       # first: one HIP runtime for both libraries
@@ -206,10 +209,12 @@ def main():
     # every rank: TILES_PER_GPU engines (HIP streams) on its GPU, one tile of the step each
     engines = [TileEngine(net, local_rank, weights) for _ in range(TILES_PER_GPU)]
     eng = engines[0]
-    rows, cols = GRIDS[world]
+    rows, cols = GRIDS[world] if not opts.debug_grid else \
+        tuple(int(v) for v in opts.debug_grid.split('x'))
     H, W = rows * TILE, cols * TILE
     rects = tile_grid((H, W), TILE)
-    assert len(rects) == TILES_PER_GPU * world
+    assert len(rects) % world == 0 and (opts.debug_grid or len(rects) == TILES_PER_GPU * world)
+    tiles_per_rank = len(rects) // world
     content_weight = {'conv4_2': 0.05}
     style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
 
@@ -273,7 +278,7 @@ def main():
         return evaluate_end()
 
     grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
-                 for _ in range(TILES_PER_GPU)]
+                 for _ in range(tiles_per_rank)]
     tile_bufs = {}
 
     def cut(rect, roll):

@@ -14,6 +14,8 @@ The image lives un-rolled on the master engine; the seam-suppression shift of an
 passed down as ``roll`` and applied as an index offset when tiles are cut and put back.
 """
 
+import os
+
 import numpy as np
 
 from . import image_ops
@@ -39,7 +41,7 @@ class TileFarm:
     """One host process, one engine per entry of ``devices`` (the reference's ``--devices``)."""
 
     def __init__(self, net, devices=(0,), weights=None, verbose=True, engines=None,
-                 streams_per_device=4):
+                 streams_per_device=4, force_staging=None):
         """``streams_per_device``: up to this many engines (each with its own HIP stream and
         activation buffers) are created per GPU, lazily, when a step has more tiles than GPUs.
         Tiles of one step then overlap on a GPU, which fills the tails and launch gaps of tiles
@@ -47,6 +49,12 @@ class TileFarm:
         33.3 -> 27.2 ms, 16 x 256^2 tiles 25.9 -> 17.2 ms; 1024^2 tiles gain ~2 %)."""
         self.net = net
         self.verbose = verbose
+        # force_staging (or STX_FARM_FORCE_STAGING=1): treat every engine but the master as if it
+        # lived on another GPU, i.e. route its tiles through the master-side staging buffers and
+        # the cross-engine copies.  On a one-GPU box this runs the multi-GPU leg's code (the
+        # copies become device-local); results must not change.
+        self.force_staging = bool(int(os.environ.get('STX_FARM_FORCE_STAGING', '0'))) \
+            if force_staging is None else bool(force_staging)
         self.owns_engines = engines is None
         self.devices = list(devices)
         self.weights = weights
@@ -248,7 +256,7 @@ class TileFarm:
             if ei == 0:
                 image_ops.cut_tile(self.master, img, roll, rect, tile)
                 stage = None
-            elif engines[ei].device == self.master.device:
+            elif engines[ei].device == self.master.device and not self.force_staging:
                 # another stream of the master GPU: its buffers are directly addressable
                 image_ops.cut_tile(self.master, img, roll, rect, tile)
                 stage = None

@@ -1,0 +1,52 @@
+"""bench.py's one-process-per-GPU protocol on a ONE-GPU box: two ranks share GPU 0
+(STX_BENCH_DEBUG_ONE_GPU=1; tiles travel over gloo through host memory instead of RCCL / xGMI).
+Same code path as `--gpus 2` otherwise: rank 0 owns the image and the optimizer, the weights
+arrive by broadcast, the shift travels with the tiles, both ranks evaluate four tiles per step.
+The tiles of a step are independent, so the loss after a few steps must not depend on how many
+ranks shared the work: the 2-rank run on a 2048 x 4096 image is compared with the same image
+evaluated by a single process."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _line(stdout):
+    rows = [l for l in stdout.splitlines() if l.startswith('{')]
+    assert rows, stdout[-2000:]
+    return json.loads(rows[-1])
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_bench_matches_single_process_loss():
+    env = dict(os.environ, STX_BENCH_DEBUG_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    common = ['--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-wall-clock',
+              '--steady-seconds', '0']
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                          '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                          str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2'] + common,
+                         env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=800)
+    assert two.returncode == 0, two.stdout[-3000:]
+    a = _line(two.stdout)
+    assert a['n_gpus'] == 2 and a['config']['tiles_per_step'] == 8
+    one = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1',
+                          '--debug-grid', '2x4'] + common, env=env, cwd=REPO,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=800)
+    assert one.returncode == 0, one.stdout[-3000:]
+    b = _line(one.stdout)
+    assert b['config']['tiles_per_step'] == 8
+    assert a['config']['final_loss'] == pytest.approx(b['config']['final_loss'], rel=1e-6)

@@ -129,3 +129,37 @@ def test_config4_miniature_matches_reference_run(golden):
     # 4 tiles x (3 + 1) evaluations at the first scale, 9 tiles x (2 + 1) at the second
     assert farm.tile_evals == 4 * (3 + 1) + 9 * (2 + 1)
     farm.close()
+
+
+def test_farm_staged_leg_equals_direct_leg():
+    """The multi-GPU leg of TileFarm.eval_sc_grad -- master-side staging buffers, the worker's
+    pull of its tile, the master's pull of the gradient (xGMI peer copies on an 8-GPU node) --
+    forced on ONE GPU: engines 1..3 are treated as remote.  Loss and stitched gradient must be
+    bit-identical to the direct leg (style_transfer.py:284-288,634-643: round-robin tiles,
+    disjoint stitch)."""
+    from style_transfer_amd import image_ops
+    net = builtin_net('vgg19')
+    weights = synthetic_weights(net, 0)
+    rng = np.random.RandomState(21)
+    img = rng.uniform(-110, 120, (3, 150, 170)).astype(np.float32)
+    style = rng.uniform(-110, 120, (3, 64, 72)).astype(np.float32)
+    cl, cw = ['conv4_2'], {'conv4_2': 0.05}
+    sl = ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+    sw = {l: 0.2 for l in sl}
+    results = []
+    for staged in (False, True):
+        farm = TileFarm(net, [0], weights, verbose=False, force_staging=staged)
+        np.random.seed(3)
+        contents = [farm.prepare_features_device(img, cl, 64, passes=2)]
+        feats = farm.prepare_features_device(style, sl, 64, passes=1)
+        styles = [{l: farm.gram_matrix(f) for l, f in feats.items()}]
+        farm.set_contents_and_styles(contents, styles)
+        eng = farm.master
+        d_img, d_grad = eng.to_device(img), eng.empty(img.shape).zero()
+        loss = farm.eval_sc_grad(d_img, d_grad, (24, -16), cl, sl, {}, cw, sw, 64)   # 3 x 3 tiles
+        assert len(farm.engines) == 4 and farm.tile_evals == 9
+        assert bool(farm._staging) == staged
+        results.append((loss, d_grad.get()))
+        farm.close()
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
