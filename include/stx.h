@@ -222,6 +222,18 @@ int stx_vec_dot(stx_engine *e, const float *x, const float *y, size_t n, double 
 int stx_vec_axpy(stx_engine *e, double a, const float *x, float *y, size_t n);
 int stx_vec_scale(stx_engine *e, double a, float *x, size_t n);
 int stx_vec_mean_abs(stx_engine *e, const float *x, size_t n, double *out_host_sync);
+/* The same recursion with its scalars kept on the device (no host round trip per dot product;
+ * LBFGSOptimizer.inv_hv, optimizers.py:105-121).  *_dev arguments point to STX_DEVICE doubles.
+ *   stx_vec_dot_async:      *out_dev = <x, y>            stx_vec_abs_sum_async: *out_dev = sum |x|
+ *   stx_vec_axpy_dev:       y += (float)(*a_dev / da * c1 [+ *b_dev / db * c2]) * x   (b_dev may be NULL)
+ *   stx_vec_scale_dev:      x *= (float)(c / (*den_dev / den_div))
+ * All asynchronous, ordered on the engine stream. */
+int stx_vec_dot_async(stx_engine *e, const float *x, const float *y, size_t n, double *out_dev);
+int stx_vec_abs_sum_async(stx_engine *e, const float *x, size_t n, double *out_dev);
+int stx_vec_axpy_dev(stx_engine *e, double c1, const double *a_dev, double da, double c2,
+                     const double *b_dev, double db, const float *x, float *y, size_t n);
+int stx_vec_scale_dev(stx_engine *e, double c, const double *den_dev, double den_div, float *x,
+                      size_t n);
 
 /* Per-step statistics of transfer() (style_transfer.py:808-815):
  * stats[0] = mean|avg - old|, stats[1] = sqrt(mean(xdiff^2 + ydiff^2)) with circular forward

@@ -238,6 +238,9 @@ int abs_sum_launch(hipStream_t s, const float *x, size_t n, double *out_dev, flo
                    size_t scratch_floats);
 int axpy_launch(hipStream_t s, float a, const float *x, float *y, size_t n);
 int scale_launch(hipStream_t s, float a, float *x, size_t n);
+int axpy_dev_launch(hipStream_t s, double c1, const double *a, double da, double c2, const double *b,
+                    double db, const float *x, float *y, size_t n);
+int scale_dev_launch(hipStream_t s, double c, const double *den, double den_div, float *x, size_t n);
 int step_stats_launch(hipStream_t s, const float *avg, float *old, int H, int W,
                       double *out_dev /*[2]*/, float *scratch, size_t scratch_floats);
 int to_u8_launch(hipStream_t s, const float *img, int H, int W, const float mean[3], uint8_t *out);

@@ -1378,6 +1378,34 @@ int stx_vec_mean_abs(stx_engine *e, const float *x, size_t n, double *out) {
     return STX_OK;
 }
 
+int stx_vec_dot_async(stx_engine *e, const float *x, const float *y, size_t n, double *out_dev) {
+    if (!e || !x || !y || !out_dev) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return dot_launch(e->stream, x, y, n, out_dev, e->red_scratch.f(),
+                      e->red_scratch.bytes / sizeof(float));
+}
+
+int stx_vec_abs_sum_async(stx_engine *e, const float *x, size_t n, double *out_dev) {
+    if (!e || !x || !out_dev) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return abs_sum_launch(e->stream, x, n, out_dev, e->red_scratch.f(),
+                          e->red_scratch.bytes / sizeof(float));
+}
+
+int stx_vec_axpy_dev(stx_engine *e, double c1, const double *a_dev, double da, double c2,
+                     const double *b_dev, double db, const float *x, float *y, size_t n) {
+    if (!e || !a_dev || !x || !y || da == 0.0 || (b_dev && db == 0.0)) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return axpy_dev_launch(e->stream, c1, a_dev, da, c2, b_dev, db, x, y, n);
+}
+
+int stx_vec_scale_dev(stx_engine *e, double c, const double *den_dev, double den_div, float *x,
+                      size_t n) {
+    if (!e || !den_dev || !x || den_div == 0.0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return scale_dev_launch(e->stream, c, den_dev, den_div, x, n);
+}
+
 int stx_vec_axpy(stx_engine *e, double a, const float *x, float *y, size_t n) {
     if (!e || !x || !y) return STX_ERR_ARG;
     STX_TRY(e->set_device());

@@ -395,6 +395,44 @@ int scale_launch(hipStream_t s, float a, float *x, size_t n) {
     return STX_OK;
 }
 
+// Coefficients that live on the device (the L-BFGS two-loop recursion: every dot product feeds the
+// next axpy, optimizers.py:105-121).  The coefficient is formed in double exactly as the host
+// form does -- a / da * c1 + b / db * c2 -- and rounded to float once.
+__global__ __launch_bounds__(256) void axpy_dev_kernel(double c1, const double *__restrict__ a,
+                                                       double da, double c2,
+                                                       const double *__restrict__ b, double db,
+                                                       const float *__restrict__ x,
+                                                       float *__restrict__ y, size_t n) {
+    double coef = a[0] / da * c1;
+    if (b) coef += b[0] / db * c2;
+    const float f = (float)coef;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = f * x[i] + y[i];
+}
+
+int axpy_dev_launch(hipStream_t s, double c1, const double *a, double da, double c2, const double *b,
+                    double db, const float *x, float *y, size_t n) {
+    axpy_dev_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(c1, a, da, c2, b, db,
+                                                                                 x, y, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// x *= c / (den[0] / den_div)
+__global__ __launch_bounds__(256) void scale_dev_kernel(double c, const double *__restrict__ den,
+                                                        double den_div, float *__restrict__ x,
+                                                        size_t n) {
+    const float f = (float)(c / (den[0] / den_div));
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        x[i] = f * x[i];
+}
+
+int scale_dev_launch(hipStream_t s, double c, const double *den, double den_div, float *x, size_t n) {
+    scale_dev_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(c, den, den_div, x, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
 // ------------------------------------------------------------------------------ statistics ---
 __global__ __launch_bounds__(256) void step_stats_kernel(const float *__restrict__ avg,
                                                          float *__restrict__ old, int H, int W,

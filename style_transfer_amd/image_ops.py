@@ -79,6 +79,41 @@ def axpy(engine, a, x, y):
     lib.call('stx_vec_axpy', engine.handle, float(a), x.ptr, y.ptr, x.size)
 
 
+class DeviceScalars:
+    """A few float64 slots on the engine's GPU for scalars that never need to visit the host."""
+
+    def __init__(self, engine, n):
+        self.engine, self.n = engine, n
+        self.array = engine.empty((n,), np.float64)
+
+    def ptr(self, i):
+        assert 0 <= i < self.n
+        return self.array.ptr + 8 * i
+
+    def free(self):
+        self.array.free()
+
+
+def dot_async(engine, x, y, out_ptr):
+    """*out_ptr (device double) = <x, y>; no synchronisation."""
+    lib.call('stx_vec_dot_async', engine.handle, x.ptr, y.ptr, x.size, out_ptr)
+
+
+def abs_sum_async(engine, x, out_ptr):
+    lib.call('stx_vec_abs_sum_async', engine.handle, x.ptr, x.size, out_ptr)
+
+
+def axpy_dev(engine, c1, a_ptr, da, x, y, c2=0.0, b_ptr=None, db=1.0):
+    """y += float(*a / da * c1 [+ *b / db * c2]) * x with a, b device doubles."""
+    lib.call('stx_vec_axpy_dev', engine.handle, float(c1), a_ptr, float(da), float(c2), b_ptr,
+             float(db), x.ptr, y.ptr, x.size)
+
+
+def scale_dev(engine, c, den_ptr, x, den_div=1.0):
+    """x *= float(c / (*den / den_div)) with den a device double."""
+    lib.call('stx_vec_scale_dev', engine.handle, float(c), den_ptr, float(den_div), x.ptr, x.size)
+
+
 def scale(engine, a, x):
     lib.call('stx_vec_scale', engine.handle, float(a), x.ptr, x.size)
 

@@ -85,6 +85,10 @@ SIGNATURES = {
     'stx_vec_axpy': [_vp, _d, _vp, _vp, _sz],
     'stx_vec_scale': [_vp, _d, _vp, _sz],
     'stx_vec_mean_abs': [_vp, _vp, _sz, c_double_p],
+    'stx_vec_dot_async': [_vp, _vp, _vp, _sz, _vp],
+    'stx_vec_abs_sum_async': [_vp, _vp, _sz, _vp],
+    'stx_vec_axpy_dev': [_vp, _d, _vp, _d, _d, _vp, _d, _vp, _vp, _sz],
+    'stx_vec_scale_dev': [_vp, _d, _vp, _d, _vp, _sz],
     'stx_image_step_stats': [_vp, _vp, _vp, _i, _i, c_double_p],
     'stx_image_to_u8': [_vp, _vp, _i, _i, c_float_p, _vp],
     'stx_op_conv_forward': [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp],

@@ -75,7 +75,14 @@ class AdamOptimizer:
 
 
 class LBFGSOptimizer:
-    """L-BFGS with fixed-size steps, no line search (optimizers.py:64-138)."""
+    """L-BFGS with fixed-size steps, no line search (optimizers.py:64-138).
+
+    The two-loop recursion never leaves the GPU: every dot product lands in a device scalar and
+    the axpy / scale that consumes it reads the coefficient from there (stx_vec_*_dev), so a
+    step costs one host synchronisation -- the curvature test ``s.y > 1e-10`` that decides
+    whether the pair is kept -- instead of one per dot product (~40 at a full memory).
+    Image-sized work arrays come from a pool and are reused across steps (raw device
+    allocations synchronise the whole GPU)."""
 
     def __init__(self, engine, params, initial_step=0.1, n_corr=10):
         self.engine = engine
@@ -84,9 +91,27 @@ class LBFGSOptimizer:
         self.xy = np.zeros(2, np.int32)
         self.loss, self.grad = None, None
         self.sk, self.yk, self.syk = [], [], []
+        self._pool = []
+        # slots 0..n_corr-1: the s_i . q of the first loop; n_corr: y.y / sum|s|; n_corr+1: y_i . q
+        self._scalars = image_ops.DeviceScalars(engine, n_corr + 2)
+
+    # ---- image-sized scratch arrays, reused
+    def _take(self, like):
+        for i, a in enumerate(self._pool):
+            if a.shape == like.shape:
+                return self._pool.pop(i)
+        return self.engine.empty(like.shape)
+
+    def _give(self, *arrays):
+        self._pool.extend(arrays)
+
+    def _drop_pool(self):
+        for a in self._pool:
+            a.free()
+        self._pool = []
 
     def _copy(self, src):
-        return self.engine.empty(src.shape).copy_from(src)
+        return self._take(src).copy_from(src)
 
     def update(self, opfunc):
         eng = self.engine
@@ -96,7 +121,10 @@ class LBFGSOptimizer:
         s = self.inv_hv(self.grad)
         image_ops.scale(eng, -1.0, s)
         if not self.sk:
-            image_ops.scale(eng, self.initial_step / image_ops.mean_abs(eng, s), s)
+            # s *= initial_step / mean|s|
+            image_ops.abs_sum_async(eng, s, self._scalars.ptr(self.n_corr))
+            image_ops.scale_dev(eng, self.initial_step, self._scalars.ptr(self.n_corr), s,
+                                den_div=s.size)
         elif len(self.sk) < self.n_corr:
             image_ops.scale(eng, len(self.sk) / self.n_corr, s)
         image_ops.axpy(eng, 1.0, s, self.params)
@@ -109,36 +137,47 @@ class LBFGSOptimizer:
         return self.params, loss
 
     def store_curvature_pair(self, s, y):
-        sy = image_ops.dot(self.engine, s, y)
+        sy = image_ops.dot(self.engine, s, y)          # the step's one host synchronisation
         if sy > 1e-10:
             self.sk.append(s), self.yk.append(y), self.syk.append(sy)
         else:
-            s.free(), y.free()
+            self._give(s, y)
         if len(self.sk) > self.n_corr:
-            self.sk[0].free(), self.yk[0].free()
+            self._give(self.sk[0], self.yk[0])
             self.sk, self.yk, self.syk = self.sk[1:], self.yk[1:], self.syk[1:]
 
     def inv_hv(self, p):
-        eng = self.engine
+        eng, sc = self.engine, self._scalars
         p = self._copy(p)
-        alphas = []
-        for s, y, sy in zip(self.sk[::-1], self.yk[::-1], self.syk[::-1]):
-            alphas.append(image_ops.dot(eng, s, p) / sy)
-            image_ops.axpy(eng, -alphas[-1], y, p)
-        if self.sk:
+        m = len(self.sk)
+        for j in range(m - 1, -1, -1):                  # newest to oldest
+            # alpha_j = s_j . p / sy_j ;  p -= alpha_j y_j
+            image_ops.dot_async(eng, self.sk[j], p, sc.ptr(j))
+            image_ops.axpy_dev(eng, -1.0, sc.ptr(j), self.syk[j], self.yk[j], p)
+        if m:
             y = self.yk[-1]
-            image_ops.scale(eng, self.syk[-1] / image_ops.dot(eng, y, y), p)
-        for s, y, sy, alpha in zip(self.sk, self.yk, self.syk, alphas[::-1]):
-            beta = image_ops.dot(eng, y, p) / sy
-            image_ops.axpy(eng, alpha - beta, s, p)
+            image_ops.dot_async(eng, y, y, sc.ptr(self.n_corr))
+            image_ops.scale_dev(eng, self.syk[-1], sc.ptr(self.n_corr), p)      # p *= sy / y.y
+        for j in range(m):                              # oldest to newest
+            # beta = y_j . p / sy_j ;  p += (alpha_j - beta) s_j
+            image_ops.dot_async(eng, self.yk[j], p, sc.ptr(self.n_corr + 1))
+            image_ops.axpy_dev(eng, 1.0, sc.ptr(j), self.syk[j], self.sk[j], p,
+                               c2=-1.0, b_ptr=sc.ptr(self.n_corr + 1), db=self.syk[j])
         return p
 
     def roll(self, xy):
         self.xy += np.asarray(xy, np.int32)
 
     def set_params(self, last_iterate):
+        """New scale: the memory is cleared (optimizers.py:134-138) and every array of the old
+        size is released."""
+        old = self.params
         self.params = last_iterate
-        self.loss, self.grad = None, None
-        for a in self.sk + self.yk:
+        self.loss = None
+        for a in self.sk + self.yk + ([self.grad] if self.grad is not None else []):
             a.free()
+        self.grad = None
         self.sk, self.yk, self.syk = [], [], []
+        self._drop_pool()
+        if old is not None and old is not last_iterate:
+            old.free()
