@@ -552,6 +552,42 @@ ConvConfig wino4_config(int geometry) {
     return c;
 }
 
+// Patch geometry of a launch.  All three compute identical results, so the choice is free; what
+// differs is how much of the last patch row / column is padding and how evenly whole rounds of
+// 256 workgroups (one per CU) come out, which matters for the odd planes of a pyramid (a
+// 724-pixel tile has 91 x 91 and 46 x 46 planes: 4 x 64 patches waste 41 % of a 91-pixel row).
+// Cost of a candidate = the K-split model's estimate (wino2_splitk_factor: rounds x (chunks x
+// 2.05 us + 6 us) + the reduce pass), minimised over the split; depends on the shape only.
+static double wino4_cost(const ConvConfig &cfg, int K, int M, int H, int W) {
+    const int n_chunks = ceil_div(K, KC);
+    const long n = (long)ceil_div(M, BM) * ceil_div(H, cfg.pr) * ceil_div(W, cfg.pc);
+    const double out_mb = 4e-6 * M * (double)H * W;
+    double best_cost = 0;
+    for (int f = 1; f <= 8 && (f == 1 || n_chunks / f >= 4); ++f) {
+        const double rounds = (double)ceil_div((int)std::min<long>(n * f, 1 << 30), 256);
+        double cost = rounds * ((double)n_chunks / f * 2.05 + 6.0);
+        if (f > 1) cost += (f + 1) * out_mb / 3.0 + 5.0;
+        if (f == 1 || cost < best_cost) best_cost = cost;
+    }
+    return best_cost;
+}
+
+int wino4_pick_geometry(int K, int M, int H, int W) {
+    int best = 0;
+    double best_cost = 0;
+    for (int g = 0; g < 3; ++g) {
+        // long rows first: on a near tie the 4 x 64 patch wins (its loads and stores are the
+        // longest row segments), then 8 x 32
+        const int geo = g == 0 ? 0 : g == 1 ? 2 : 1;
+        const double c = wino4_cost(wino4_config(geo), K, M, H, W);
+        if (g == 0 || c < best_cost * 0.97) {
+            best = geo;
+            best_cost = c;
+        }
+    }
+    return best;
+}
+
 template <int EPI, int TXW>
 static int wino4_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
     auto kern = conv_wino4_kernel<EPI, TXW>;

@@ -324,14 +324,15 @@ static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, Co
         if (!strcmp(algo, "wino2")) { *out = wino2_config(wino2_pick_geometry(H, W)); return true; }
         if (!strcmp(algo, "wino2a")) { *out = wino2_config(0); return true; }   // one geometry only
         if (!strcmp(algo, "wino2b")) { *out = wino2_config(1); return true; }
-        if (!strcmp(algo, "wino4")) { *out = wino4_config(wino2_pick_geometry(H, W)); return true; }
+        if (!strcmp(algo, "wino4")) { *out = wino4_config(wino4_pick_geometry(K, M, H, W)); return true; }
+        if (!strcmp(algo, "wino4old")) { *out = wino4_config(wino2_pick_geometry(H, W)); return true; }
         if (!strcmp(algo, "wino4a")) { *out = wino4_config(0); return true; }
         if (!strcmp(algo, "wino4b")) { *out = wino4_config(1); return true; }
         if (!strcmp(algo, "wino4c")) { *out = wino4_config(2); return true; }
         if (!strcmp(algo, "wino1")) { *out = wino_config_by_id(M >= 64 ? 0 : 1); return true; }
     }
     if (!e->winograd) return false;
-    *out = M > 32 ? wino4_config(wino2_pick_geometry(H, W)) : wino_config_by_id(1);
+    *out = M > 32 ? wino4_config(wino4_pick_geometry(K, M, H, W)) : wino_config_by_id(1);
     return true;
 }
 
@@ -483,7 +484,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     // all at once; the four-wave kernel has to fetch them in four dependent round trips (measured
     // 0.70 vs 0.44 ms on conv1_2's backward), so the injecting layers stay on the eight-wave one.
     // Same arithmetic, same results.
-    if (inj && cfg.id >= 210 && !getenv("STX_CONV_ALGO")) cfg = wino2_config(cfg.id - 210 == 1 ? 1 : 0);
+    if (inj && cfg.id >= 210 && !getenv("STX_CONV_ALGO")) cfg = wino2_config(wino2_pick_geometry(p.H, p.W));
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
