@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -498,7 +499,9 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
 
 // Runs the layers needed for `needed` blobs, in graph order.  `relu_blob` (or -1) is rectified
 // even when no ReLU layer follows it (np.maximum(0, .) at style_transfer.py:426,567).
-int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
+// `after_blob` (optional) is called as soon as a blob is complete, before the next layer is queued.
+int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
+            const std::function<int(int)> *after_blob = nullptr) {
     int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
@@ -523,6 +526,10 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
             bool pooled = false;
             STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled));
             if (pooled) pooled_layer = pool_li;
+            if (after_blob) {
+                STX_TRY((*after_blob)(L.top_blob));
+                if (pooled) STX_TRY((*after_blob)(pool->top_blob));
+            }
         } else if ((int)li == pooled_layer) {
             continue;
         } else {
@@ -531,6 +538,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob) {
                                         t.data.f()));
             if (t.relu || L.top_blob == relu_blob)
                 STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
+            if (after_blob) STX_TRY((*after_blob)(L.top_blob));
         }
     }
     return STX_OK;
@@ -1022,8 +1030,6 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     const int data_blob = e->layers[0].top_blob;
     Blob &in = e->blobs[data_blob];
     STX_TRY(copy_in(e, in.data.ptr, img, img_mem, in.count() * sizeof(float)));
-    STX_TRY(begin_timing(e));
-    STX_TRY(forward(e, needed, order[0].blob));
 
     PendingLoss pl;
     pl.out = loss_out;
@@ -1039,15 +1045,18 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         ContentWindow win;
     };
     std::vector<std::vector<Term>> terms(order.size());
-    STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
-    STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
     while (e->ev_tap.size() < order.size()) {
         hipEvent_t ev;
         STX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         e->ev_tap.push_back(ev);
     }
     while (e->sgrad_tap.size() < order.size()) e->sgrad_tap.emplace_back(new DevBuf);
-    for (size_t k = 0; k < order.size(); ++k) {
+    // Loss terms of tap k (Gram -> G - Gs -> SYMM, content residual sums).  With one stream they
+    // are queued the moment the tapped blob is complete, in the middle of the forward pass, while
+    // the blob is still in the L2 / Infinity Cache the convolution just wrote it through (the
+    // shallow blobs were re-fetched from HBM when all taps ran after the forward pass: 1.1 GB
+    // per tile by PMC); with a side stream (STX_SIDE_STREAM=1) they run after it, as before.
+    auto launch_terms = [&](size_t k) -> int {
         const Tap &tp = order[k];
         Blob &b = e->blobs[tp.blob];
         const double lw = tp.t->layer_weight;
@@ -1145,6 +1154,19 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             }
         }
         STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
+        return STX_OK;
+    };
+    const bool interleave = e->side == e->stream;
+    const std::function<int(int)> hook = [&](int blob) -> int {
+        const int k = tap_of[blob];
+        return k >= 0 ? launch_terms((size_t)k) : STX_OK;
+    };
+    STX_TRY(begin_timing(e));
+    STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr));
+    if (!interleave) {
+        STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
+        STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
+        for (size_t k = 0; k < order.size(); ++k) STX_TRY(launch_terms(k));
     }
 
     // Adds the terms of tap k to its blob's diff with stand-alone kernels (used for the deepest
