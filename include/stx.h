@@ -201,13 +201,16 @@ int stx_image_resample(stx_engine *e, const float *src, int channels, int H, int
 /* TV + p-norm + auxiliary-image terms of eval_loss_and_grad (style_transfer.py:709-733,
  * num_utils.py:74-82,150-162): grad += tv_scale*d tv_norm(img/127.5, tv_power)
  *                                    + p_scale*d p_norm((img+mean-127.5)/127.5, p_power)
- *                                    + aux_scale*(img-aux)/127.5;
+ *                                    + aux_scale*(img-aux')/127.5;
  * *loss_out (host, written at stx_sync) = tv_scale*TV + p_scale*P + aux_scale*A.
- * A scale of 0 disables a term; aux may be NULL.  mean_bgr is a host array of 3 floats. */
+ * A scale of 0 disables a term; aux may be NULL.  mean_bgr is a host array of 3 floats.
+ * aux_roll_xy (or NULL = no shift): the reference rolls the image by the iteration's shift but
+ * not its auxiliary image (style_transfer.py:729-733,777-786), so in the un-rolled frame used here
+ * aux'[y][x] = aux[(y + roll_xy[1]) mod H][(x + roll_xy[0]) mod W]. */
 int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,
                            const float mean_bgr[3], double tv_scale, double tv_power,
                            double p_scale, double p_power, const float *aux, double aux_scale,
-                           double *loss_out);
+                           const int aux_roll_xy[2], double *loss_out);
 
 /* AdamOptimizer.update after the gradient is known (optimizers.py:35-42), fused:
  *   g1 = b1*g1 + (1-b1)*grad; g2 = b2*g2 + (1-b2)*grad^2; p1 likewise on the new params;

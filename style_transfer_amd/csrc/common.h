@@ -228,8 +228,8 @@ int resample_launch(hipStream_t s, int axis, const float *src, int C, int H, int
                     int OH, int OW, const int *bounds, const double *k, int ksize, int clamp);
 int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
                         const float mean[3], float tv_scale, float tv_power, float p_scale,
-                        float p_power, const float *aux, float aux_scale, double *loss_terms /*[3]*/,
-                        float *scratch, size_t scratch_floats);
+                        float p_power, const float *aux, float aux_scale, int aux_rx, int aux_ry,
+                        double *loss_terms /*[3]*/, float *scratch, size_t scratch_floats);
 int adam_launch(hipStream_t s, float *params, const float *grad, float *g1, float *g2, float *p1,
                 float *avg, size_t n, double lr, double b1, double b2, double bp1, double c1,
                 double c2, double cp);

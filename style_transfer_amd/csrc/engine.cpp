@@ -1343,7 +1343,8 @@ int stx_image_resample(stx_engine *e, const float *src, int channels, int H, int
 
 int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, int W,
                            const float mean_bgr[3], double tv_scale, double tv_power, double p_scale,
-                           double p_power, const float *aux, double aux_scale, double *loss_out) {
+                           double p_power, const float *aux, double aux_scale,
+                           const int aux_roll_xy[2], double *loss_out) {
     if (!e || !img || !grad || !mean_bgr || H <= 0 || W <= 0) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     size_t di;
@@ -1351,7 +1352,8 @@ int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, 
     double *terms = static_cast<double *>(e->dscalars.ptr) + di;
     STX_TRY(regularizers_launch(e->stream, img, grad, H, W, mean_bgr, (float)tv_scale,
                                 (float)tv_power, (float)p_scale, (float)p_power, aux,
-                                (float)aux_scale, terms, e->red_scratch.f(),
+                                (float)aux_scale, aux_roll_xy ? aux_roll_xy[0] : 0,
+                                aux_roll_xy ? aux_roll_xy[1] : 0, terms, e->red_scratch.f(),
                                 e->red_scratch.bytes / sizeof(float)));
     STX_HIP(hipMemcpyAsync(e->dscalars_host + di, terms, 3 * sizeof(double), hipMemcpyDeviceToHost,
                            e->stream));

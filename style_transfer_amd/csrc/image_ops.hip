@@ -209,6 +209,7 @@ struct RegArgs {
     float mean[3];
     float tv_scale, tv_half_beta, p_scale, p_power, aux_scale;
     int p_int;              // p_power - 1 when that is an integer in 1..8, else 0
+    int aux_rx, aux_ry;     // the iteration's shift: the auxiliary image is NOT rolled with the image
 };
 
 __global__ __launch_bounds__(256) void regularizers_kernel(RegArgs a, float *__restrict__ partials) {
@@ -265,7 +266,13 @@ __global__ __launch_bounds__(256) void regularizers_kernel(RegArgs a, float *__r
             g = a.p_scale * (a.p_power * sg * ap1) + g;
         }
         if (a.aux != nullptr && a.aux_scale != 0.f) {
-            const float d = (v - a.aux[i]) / 127.5f;
+            // the reference rolls the image by the iteration's shift but never its auxiliary
+            // image (style_transfer.py:729-733 against 777-786): in the un-rolled frame kept here,
+            // pixel (y, x) meets aux[(y + ry) mod H][(x + rx) mod W]
+            int ay = (y + a.aux_ry) % a.H, ax = (x + a.aux_rx) % a.W;
+            if (ay < 0) ay += a.H;
+            if (ax < 0) ax += a.W;
+            const float d = (v - a.aux[(size_t)c * plane + (size_t)ay * a.W + ax]) / 127.5f;
             sums[2] += d * d;
             g = a.aux_scale * d + g;
         }
@@ -276,8 +283,8 @@ __global__ __launch_bounds__(256) void regularizers_kernel(RegArgs a, float *__r
 
 int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
                         const float mean[3], float tv_scale, float tv_power, float p_scale,
-                        float p_power, const float *aux, float aux_scale, double *loss_terms,
-                        float *scratch, size_t scratch_floats) {
+                        float p_power, const float *aux, float aux_scale, int aux_rx, int aux_ry,
+                        double *loss_terms, float *scratch, size_t scratch_floats) {
     RegArgs a;
     a.img = img;
     a.grad = grad;
@@ -292,6 +299,8 @@ int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int
     const float pm1 = p_power - 1.f;
     a.p_int = (pm1 >= 1.f && pm1 <= 8.f && pm1 == (float)(int)pm1) ? (int)pm1 : 0;
     a.aux_scale = aux_scale;
+    a.aux_rx = aux_rx;
+    a.aux_ry = aux_ry;
     const int blocks = blocks_for((size_t)3 * H * W);
     if (scratch_floats < (size_t)3 * blocks) {
         set_error("regularizers: scratch too small");

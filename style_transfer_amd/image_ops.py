@@ -46,14 +46,17 @@ class PendingScalar:
 
 
 def regularizers(engine, img, grad, mean_bgr, tv_scale, tv_power, p_scale, p_power, aux=None,
-                 aux_scale=0.0):
-    """grad += regularizer gradients; returns a PendingScalar with the loss (valid after sync)."""
+                 aux_scale=0.0, aux_roll=None):
+    """grad += regularizer gradients; returns a PendingScalar with the loss (valid after sync).
+    ``aux_roll``: the iteration's shift (x, y) -- the reference rolls the image, not the auxiliary
+    image, so the un-rolled image meets the auxiliary image displaced by it."""
     _, H, W = img.shape
     mean = (ctypes.c_float * 3)(*[float(m) for m in np.ravel(mean_bgr)])
     out = PendingScalar()
     lib.call('stx_image_regularizers', engine.handle, img.ptr, grad.ptr, H, W, mean,
              float(tv_scale), float(tv_power), float(p_scale), float(p_power),
-             aux.ptr if aux is not None else None, float(aux_scale), ctypes.byref(out._v))
+             aux.ptr if aux is not None else None, float(aux_scale),
+             _xy(aux_roll) if aux_roll is not None else None, ctypes.byref(out._v))
     return out
 
 

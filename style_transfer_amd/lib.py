@@ -79,7 +79,7 @@ SIGNATURES = {
     'stx_image_resample': [_vp, _vp, _i, _i, _i, _vp, _i, _i, c_int_p, c_double_p, _i, c_int_p,
                            c_double_p, _i, _i],
     'stx_image_regularizers': [_vp, _vp, _vp, _i, _i, c_float_p, _d, _d, _d, _d, _vp, _d,
-                               c_double_p],
+                               c_int_p, c_double_p],
     'stx_adam_step': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _d, _d, _d],
     'stx_vec_dot': [_vp, _vp, _vp, _sz, c_double_p],
     'stx_vec_axpy': [_vp, _d, _vp, _vp, _sz],

@@ -166,7 +166,7 @@ class StyleTransfer:
             reg = image_ops.regularizers(
                 self.engine, params, self.grad, self.mean, lw * args.tv_weight, args.tv_power,
                 lw * args.p_weight, args.p_power, self.aux_image,
-                lw * args.aux_weight if aux_on else 0.0)
+                lw * args.aux_weight if aux_on else 0.0, aux_roll=roll)
             self.engine.sync()
             loss += reg.value
         return loss, self.grad

@@ -375,6 +375,32 @@ def main():
     out['e2e_cfg4/saved_files'] = np.array(' '.join(saved))
     out['e2e_cfg4/image_comment'] = np.array(st.get_image_comment())
 
+    # ------- 4e. the auxiliary-image term (--aux-image, style_transfer.py:729-733): the reference
+    # rolls the image by the iteration's shift but not the auxiliary image.  One scale, 2 x 2 tiles,
+    # three Adam steps.
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png', '--aux-image', 'a.png',
+                '--size', '72', '--min-size', '72', '--tile-size', '48', '--iterations', '3',
+                '--display', 'none', '--seed', '21']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(70, 64, 72)
+    style_u8 = smooth_image(71, 60, 50)
+    aux_u8 = smooth_image(72, 64, 72)
+    log = []
+    np.random.seed(st.ARGS.seed)
+    transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                 None, Image.fromarray(aux_u8), callback=Cb())
+    out['e2e_aux/content_u8'], out['e2e_aux/style_u8'], out['e2e_aux/aux_u8'] = \
+        content_u8, style_u8, aux_u8
+    out['e2e_aux/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e_aux/log'] = np.float64(log)
+    out['e2e_aux/final_raw'] = transfer.current_raw.copy()
+
     # ----------- 4d. the six deploy prototxts the reference ships, as parsed layer tuples (data
     # for the --model reader): (name, type, bottom, top, num_output, pad, kernel,
     # stride, pool).  Two independent readings must agree: the oracle's protobuf-text parser and
