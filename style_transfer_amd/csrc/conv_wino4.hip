@@ -42,7 +42,9 @@ namespace stx {
 #ifdef STX_WINO4_TIMING   // cycle counters for tools/ubench/wino2_bench.hip
 __device__ long long g_wino4_timing[4][4];
 #define STX_T4(var) const long long var = clock64()
+#define STX_T4R(var) const long long var = wall_clock64()
 #else
+#define STX_T4R(var) const long long var = 0
 #define STX_T4(var) const long long var = 0
 #endif
 
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(WinoArgs a) {
     constexpr int TYW = 32 / TXW, PR = 4 * TYW, PC = 2 * TXW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     STX_T4(t_start);
+    STX_T4R(r_start);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = sgpr(tid >> 6);
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(WinoArgs a) {
         g_wino4_timing[wave][0] = t_mid - t_start;
         g_wino4_timing[wave][1] = t_epi - t_mid;
         g_wino4_timing[wave][2] = clock64() - t_epi;
+        g_wino4_timing[wave][3] = wall_clock64() - r_start;      // 100 MHz ticks
     }
 #endif
 }

@@ -13,6 +13,7 @@ Differences in mechanism, not in result:
 """
 
 from argparse import Namespace
+from dataclasses import dataclass
 import json
 import time
 
@@ -25,17 +26,23 @@ from .optimizers import AdamOptimizer, LBFGSOptimizer
 from .resample import resample_device
 
 
-def resize_to_fit(image, size, scale_up=False, div=1):
-    """Resizes a PIL image to fit a size x size square (style_transfer.py:963-976)."""
+def fit_size(wh, size, scale_up=False, div=1):
+    """(w, h) of a picture fitted into a size x size square, None if it is left alone: the
+    arithmetic of the reference's resize_to_fit (style_transfer.py:963-976) without the pixels,
+    so that a whole run can be planned before anything is resampled."""
     size = int(round(size)) // div * div
-    w, h = image.size
+    w, h = wh
     if not scale_up and max(w, h) <= size:
-        return image
+        return None
     if w > h:
-        new_w, new_h = size, int(round(size * h / w)) // div * div
-    else:
-        new_h, new_w = size, int(round(size * w / h)) // div * div
-    return image.resize((new_w, new_h), Image.LANCZOS)
+        return size, int(round(size * h / w)) // div * div
+    return int(round(size * w / h)) // div * div, size
+
+
+def resize_to_fit(image, size, scale_up=False, div=1):
+    """Resizes a PIL image to fit a size x size square (Lanczos), or returns it untouched."""
+    target = fit_size(image.size, size, scale_up, div)
+    return image if target is None else image.resize(target, Image.LANCZOS)
 
 
 def pyramid_sizes(size, min_size):
@@ -46,6 +53,57 @@ def pyramid_sizes(size, min_size):
         if size < min_size:
             return sizes
         sizes.append(size)
+
+
+@dataclass
+class ScalePlan:
+    """One level of the pyramid, decided before the run starts."""
+    index: int                  # 0 = coarsest
+    size: int                   # the --size of this level
+    content_wh: tuple           # picture size at this level
+    style_fit: list             # per style image: (w, h) to resample to, or None = as is
+    iterations: int
+    tiles: tuple                # (rows, columns) of the tile grid (style_transfer.py:619-632)
+
+
+def plan_scales(args, content_wh, style_whs):
+    """The whole multi-scale schedule as data (style_transfer.py:832-909): pyramid sizes from
+    --min-size up to --size, the picture size of every level, how each style image is fitted
+    (--style-scale / --max-style-size / --style-scale-up; --style-multiscale keeps the
+    originals and fits them in preprocess_images instead), the iteration count (the last
+    --iterations value repeats) and the tile grid."""
+    plans = []
+    for i, size in enumerate(reversed(pyramid_sizes(args.size, args.min_size))):
+        cw, ch = fit_size(content_wh, size, scale_up=True, div=args.div)
+        fits = []
+        for wh in style_whs:
+            if args.style_multiscale:
+                fits.append(None)
+            elif args.style_scale >= 32:
+                fits.append(fit_size(wh, args.style_scale, scale_up=True, div=args.div))
+            else:
+                target = round(size * args.style_scale)
+                if args.max_style_size is not None:
+                    target = min(target, args.max_style_size)
+                fits.append(fit_size(wh, target, scale_up=args.style_scale_up, div=args.div))
+        plans.append(ScalePlan(i, size, (cw, ch), fits,
+                               args.iterations[min(i, len(args.iterations) - 1)],
+                               ((ch - 1) // args.tile_size + 1, (cw - 1) // args.tile_size + 1)))
+    return plans
+
+
+def style_pyramid(args):
+    """Sizes at which every style image is processed: [None] (as given) unless
+    --style-multiscale MIN MAX asks for a sqrt(2) ladder (style_transfer.py:493-503)."""
+    if not args.style_multiscale:
+        return [None]
+    vmin, vmax = args.style_multiscale
+    sizes = [vmax]
+    while True:
+        nxt = int(round(sizes[-1] / np.sqrt(2)))
+        if nxt < max(32, vmin):
+            return sizes
+        sizes.append(nxt)
 
 
 def parse_weights(args, master_weight):
@@ -106,50 +164,44 @@ class StyleTransfer:
         return self.get_image() if self.current_raw is not None else None
 
     # -------------------------------------------------------------------------- preprocessing
+    def _style_variants(self, index, image):
+        """The resamplings of one style image that contribute a Gram each: smallest ladder size
+        first, stopping after the first one that no longer shrinks the picture; variants under
+        32 pixels are skipped (style_transfer.py:505-531)."""
+        for size in reversed(style_pyramid(self.args)):
+            if size is None:
+                yield image
+                return
+            scaled = resize_to_fit(image, size, div=self.args.div)
+            last = max(scaled.size) == max(image.size)
+            if min(scaled.size) >= 32:
+                print('Processing style {} at {}x{}.'.format(index + 1, *scaled.size))
+                yield scaled
+            if last:
+                return
+
     def preprocess_images(self, content_images, style_images, content_layers, style_layers):
-        """Style Grams (mean over all style images and scales) and tiling-averaged content
-        features (style_transfer.py:488-554)."""
-        args, farm = self.args, self.farm
+        """Targets of one scale: the style Grams, averaged with equal weight over every style
+        image and ladder size, and the tiling-averaged content features
+        (style_transfer.py:488-554).  Everything stays on the master GPU."""
+        farm, tile = self.farm, self.args.tile_size
         print('Preprocessing the style image(s)...')
-        sizes = [None]
-        if args.style_multiscale:
-            vmin, vmax = args.style_multiscale
-            size, sizes = vmax, [vmax]
-            while True:
-                size = int(round(size / np.sqrt(2)))
-                if size < max(32, vmin):
-                    break
-                sizes.append(size)
         if not self.styles:
-            grams, count = {}, 0
-            for i, image in enumerate(style_images):
-                too_big = False
-                for size in reversed(sizes):
-                    if too_big:
-                        break
-                    if size:
-                        scaled = resize_to_fit(image, size, div=args.div)
-                        if max(scaled.size) == max(image.size):
-                            too_big = True
-                        if min(scaled.size) < 32:
-                            continue
-                        print('Processing style {} at {}x{}.'.format(i + 1, *scaled.size))
-                    else:
-                        scaled = image
-                    feats = farm.prepare_features_device(self.pil_to_image(scaled), style_layers,
-                                                         args.tile_size, passes=1)
+            total, count = {}, 0
+            for index, image in enumerate(style_images):
+                for variant in self._style_variants(index, image):
+                    feats = farm.prepare_features_device(self.pil_to_image(variant), style_layers,
+                                                         tile, passes=1)
                     for layer, feat in feats.items():
                         gram = farm.gram_matrix(feat)
                         feat.free()
-                        grams[layer] = gram if layer not in grams else grams[layer] + gram
+                        total[layer] = gram if layer not in total else total[layer] + gram
                     count += 1
-            for gram in grams.values():
-                gram /= count
-            self.styles.append(grams)
+            self.styles.append({layer: gram / count for layer, gram in total.items()})
         print('Preprocessing the content image(s)...')
-        for image in content_images:
-            self.contents.append(farm.prepare_features_device(
-                self.pil_to_image(image), content_layers, args.tile_size, passes=10))
+        self.contents += [farm.prepare_features_device(self.pil_to_image(image), content_layers,
+                                                       tile, passes=10)
+                          for image in content_images]
 
     # ------------------------------------------------------------------------------ objective
     def eval_loss_and_grad(self, params, sc_args):
@@ -224,63 +276,52 @@ class StyleTransfer:
         return self.current_raw
 
     # ------------------------------------------------------------------------- all scales
+    def _first_iterate(self, plan, initial_image):
+        """The start image of the coarsest level and its optimizer (style_transfer.py:883-900):
+        the supplied --init-image, or uniform noise drawn from the global RNG."""
+        args = self.args
+        w, h = plan.content_wh
+        if initial_image:
+            start = self.pil_to_image(initial_image.resize((w, h), Image.LANCZOS))
+        else:
+            start = self.pil_to_image(np.random.uniform(0, 255, size=(h, w, 3)))
+        self.img = self.engine.to_device(start)
+        if args.optimizer == 'adam':
+            # an image that is already a picture starts with a biased first moment
+            return AdamOptimizer(self.engine, self.img, step_size=args.step_size,
+                                 bp1=1 - (1 / args.avg_window), decay=args.step_decay[0],
+                                 power=args.step_decay[1], biased_g1=bool(initial_image))
+        if args.optimizer == 'lbfgs':
+            return LBFGSOptimizer(self.engine, self.img)
+        raise ValueError(args.optimizer)
+
     def transfer_multiscale(self, content_images, style_images, initial_image=None, aux_image=None,
                             callback=None):
-        """The sqrt(2) pyramid from --min-size up to --size (style_transfer.py:832-909)."""
+        """Runs the planned pyramid (plan_scales), coarsest level first; every level starts from
+        the Lanczos-upsampled averaged iterate of the one before (style_transfer.py:832-909)."""
         args = self.args
-        sizes = pyramid_sizes(args.size, args.min_size)
+        if any(image.size != content_images[0].size for image in content_images):
+            raise ValueError('All of the content images must be the same size')
+        plans = plan_scales(args, content_images[0].size, [image.size for image in style_images])
         if callback is not None and hasattr(callback, 'set_steps'):
-            callback.set_steps(sum(args.iterations[min(i, len(args.iterations) - 1)]
-                                   for i in range(len(sizes))))
-        output_raw = None
-        for i, size in enumerate(reversed(sizes)):
-            content_scaled = []
-            for image in content_images:
-                if image.size != content_images[0].size:
-                    raise ValueError('All of the content images must be the same size')
-                content_scaled.append(resize_to_fit(image, size, scale_up=True, div=args.div))
-            w, h = content_scaled[0].size
-            print('\nScale %d, image size %dx%d.\n' % (i + 1, w, h))
-            style_scaled = []
-            for image in style_images:
-                if args.style_multiscale:
-                    style_scaled.append(image)
-                elif args.style_scale >= 32:
-                    style_scaled.append(resize_to_fit(image, args.style_scale, scale_up=True,
-                                                      div=args.div))
-                else:
-                    style_size = round(size * args.style_scale)
-                    if args.max_style_size is not None:
-                        style_size = min(style_size, args.max_style_size)
-                    style_scaled.append(resize_to_fit(image, style_size,
-                                                      scale_up=args.style_scale_up, div=args.div))
+            callback.set_steps(sum(plan.iterations for plan in plans))
+        previous = None
+        for plan in plans:
+            w, h = plan.content_wh
+            print('\nScale %d, image size %dx%d.\n' % (plan.index + 1, w, h))
+            contents = [image.resize((w, h), Image.LANCZOS) for image in content_images]
+            styles = [image if fit is None else image.resize(fit, Image.LANCZOS)
+                      for image, fit in zip(style_images, plan.style_fit)]
             if aux_image:
-                aux_scaled = aux_image.resize(content_scaled[0].size, Image.LANCZOS)
                 if self.aux_image is not None:
                     self.aux_image.free()
-                self.aux_image = self.engine.to_device(self.pil_to_image(aux_scaled))
-            if output_raw is not None:      # not the first scale: upsample the averaged iterate
-                # model.resize_image (style_transfer.py:399-401): Lanczos, on the GPU
-                self.img = resample_device(self.engine, output_raw, (h, w))
-                self.optimizer.set_params(self.img)
+                self.aux_image = self.engine.to_device(
+                    self.pil_to_image(aux_image.resize((w, h), Image.LANCZOS)))
+            if previous is None:
+                self.optimizer = self._first_iterate(plan, initial_image)
             else:
-                biased_g1 = True
-                if initial_image:
-                    initial_image = initial_image.resize(content_scaled[0].size, Image.LANCZOS)
-                    start = self.pil_to_image(initial_image)
-                else:
-                    start = self.pil_to_image(np.random.uniform(0, 255, size=(h, w, 3)))
-                    biased_g1 = False
-                self.img = self.engine.to_device(start)
-                if args.optimizer == 'adam':
-                    self.optimizer = AdamOptimizer(
-                        self.engine, self.img, step_size=args.step_size,
-                        bp1=1 - (1 / args.avg_window), decay=args.step_decay[0],
-                        power=args.step_decay[1], biased_g1=biased_g1)
-                elif args.optimizer == 'lbfgs':
-                    self.optimizer = LBFGSOptimizer(self.engine, self.img)
-                else:
-                    raise ValueError(args.optimizer)
-            iters_i = args.iterations[min(i, len(args.iterations) - 1)]
-            output_raw = self.transfer(iters_i, content_scaled, style_scaled, callback)
+                # model.resize_image (style_transfer.py:399-401): Lanczos, on the GPU
+                self.img = resample_device(self.engine, previous, (h, w))
+                self.optimizer.set_params(self.img)
+            previous = self.transfer(plan.iterations, contents, styles, callback)
         return self.current_output

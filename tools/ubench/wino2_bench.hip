@@ -60,8 +60,9 @@ static void run(int K, int M, int H, int W, int epilogue) {
         long long t4[4][4];
         hipMemcpyFromSymbol(t4, HIP_SYMBOL(stx::g_wino4_timing), sizeof(t4));
         for (int wv = 0; wv < 4; wv += 3)
-            printf("   wave %d: prologue %6lld  chunk loop %7lld (%.0f per chunk)  epilogue %6lld cycles\n", wv,
-                   t4[wv][0], t4[wv][1], (double)t4[wv][1] / ((K + 7) / 8), t4[wv][2]);
+            printf("   wave %d: prologue %6lld  chunk loop %7lld (%.0f per chunk)  epilogue %6lld cycles; workgroup %.2f us at %.0f MHz\n", wv,
+                   t4[wv][0], t4[wv][1], (double)t4[wv][1] / ((K + 7) / 8), t4[wv][2], t4[wv][3] / 100.0,
+                   (double)(t4[wv][0] + t4[wv][1] + t4[wv][2]) / (t4[wv][3] / 100.0));
     }
 #endif
 #ifdef STX_WINO2_TIMING
