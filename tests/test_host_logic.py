@@ -129,3 +129,25 @@ def test_resample_coefficients_reproduce_pillow(hw, method):
     ref = np.stack([np.asarray(Image.fromarray(a[c]).resize((hw[1], hw[0]), pil_method))
                     for c in range(3)])
     assert np.array_equal(resample.resample_host(a, hw, method), ref)
+
+
+def test_schedule_is_planned_up_front():
+    """plan_scales: pyramid sizes, per-level picture and style sizes, iterations and tile grids of
+    BASELINE configs 3 and 4 (style_transfer.py:832-909,619-632)."""
+    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--size', '2048', '--tile-size',
+                                           '1024'], config_py=False)
+    plans = transfer.plan_scales(args, (2048, 2048), [(1500, 1000)])
+    assert [p.size for p in plans] == [256, 362, 512, 724, 1024, 1448, 2048]
+    assert [p.iterations for p in plans] == [200] + [100] * 6
+    assert [p.tiles for p in plans] == [(1, 1)] * 5 + [(2, 2)] * 2
+    assert sum(p.iterations * p.tiles[0] * p.tiles[1] for p in plans) == 1400     # tile-iterations
+    assert plans[0].style_fit == [(256, 171)] and plans[-1].style_fit == [None]   # never scaled up
+    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--size', '4096', '--tile-size',
+                                           '1024', '-o', 'lbfgs'], config_py=False)
+    plans = transfer.plan_scales(args, (4096, 4096), [(4096, 4096)])
+    assert [p.tiles for p in plans][-2:] == [(3, 3), (4, 4)] and plans[-2].content_wh == (2896, 2896)
+    assert transfer.fit_size((400, 300), 800) is None
+    assert transfer.fit_size((400, 300), 250, div=32) == (224, 160)
+    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--style-multiscale', '100',
+                                           '400'], config_py=False)
+    assert transfer.style_pyramid(args) == [400, 283, 200, 141, 100]
