@@ -131,7 +131,8 @@ int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int 
 
 /* One tapped blob of an SCGradRequest: layer_weights[layer], content_weight[layer] (0 = not a
  * content layer), style_weight[layer] (0 = not a style layer) -- style_transfer.py:158-161,570,
- * 579-580,591-593.  Deep-Dream taps (dd_layers) are not implemented (default dd_weight 0). */
+ * 579-580,591-593 -- and dd_weight[layer] (0 = not a Deep-Dream layer): loss -= lw*dd*1/2|F|^2,
+ * diff -= lw*dd*normalize(F), style_transfer.py:602-604. */
 typedef struct stx_tap {
     const char *layer;
     double layer_weight;
@@ -139,6 +140,8 @@ typedef struct stx_tap {
     double content_weight;
     int is_style;
     double style_weight;
+    int is_dd;
+    double dd_weight;
 } stx_tap;
 
 /* Replaces the SCGradRequest branch of TileWorker.process_one_request + CaffeModel.

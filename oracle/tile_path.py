@@ -63,10 +63,11 @@ class OracleModel:
 
     # ---- style_transfer.py:556-612
     def sc_grad_tile(self, tile, start, content_layers, style_layers, layer_weights,
-                     content_weight, style_weight, activations=None):
-        """``activations`` (test-only, see Net.load_activations) replaces the forward results."""
+                     content_weight, style_weight, activations=None, dd_layers=(), dd_weight=None):
+        """``activations`` (test-only, see Net.load_activations) replaces the forward results.
+        ``dd_layers`` / ``dd_weight``: the Deep-Dream term (style_transfer.py:602-604)."""
         net = self.net
-        order = self.deep_to_shallow(list(content_layers) + list(style_layers))
+        order = self.deep_to_shallow(list(content_layers) + list(style_layers) + list(dd_layers))
         net.blobs['data'].reshape(1, 3, *tile.shape[-2:])
         net.blobs['data'].data[0] = tile
         net._reshape()
@@ -96,6 +97,9 @@ class OracleModel:
                     loss += lw * style_weight[b] * half_sq_norm(gdiff) / len(self.styles)
                     diff += np.float32(lw * style_weight[b] / len(self.styles)) * \
                         l1_normalize(sgrad).reshape(feat.shape)
+            if b in dd_layers:
+                loss -= lw * dd_weight[b] * half_sq_norm(feat)
+                diff -= np.float32(lw * dd_weight[b]) * l1_normalize(feat.copy())
             if i + 1 == len(order):
                 net.backward(start=b)
             else:

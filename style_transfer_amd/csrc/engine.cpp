@@ -995,11 +995,11 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 set_error("stx_sc_grad_tile: layer '%s' is tapped twice", taps[i].layer);
                 return STX_ERR_ARG;
             }
-        if (!taps[i].is_content && !taps[i].is_style) continue;
+        if (!taps[i].is_content && !taps[i].is_style && !taps[i].is_dd) continue;
         order.push_back(Tap{blob, &taps[i]});
     }
     if (order.empty()) {
-        set_error("stx_sc_grad_tile: no content or style layer");
+        set_error("stx_sc_grad_tile: no content, style or Deep-Dream layer");
         return STX_ERR_ARG;
     }
     std::sort(order.begin(), order.end(), [](const Tap &a, const Tap &b) { return a.blob > b.blob; });
@@ -1153,6 +1153,23 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                                         (float)(lw * tp.t->style_weight / e->n_styles), ContentWindow{}});
             }
         }
+        if (tp.t->is_dd) {
+            // Deep-Dream term (style_transfer.py:602-604): the content term against a zero map with
+            // a negative weight -- loss -= lw*dd*1/2|F|^2, diff -= lw*dd*normalize(F)
+            ContentWindow win{};
+            win.C = b.channels;
+            win.fh = win.ch = b.h;
+            win.fw = win.cw = b.w;
+            size_t si;
+            STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
+            float *sums = e->scalars.f() + si;
+            {
+                ProfScope scope(e, "dream " + b.name, 0.0, e->side);
+                STX_TRY(content_sums_launch(e->side, b.data.f(), nullptr, win, sums));
+            }
+            pl.terms.push_back(LossTerm{si, -lw * tp.t->dd_weight * 0.5});
+            terms[k].push_back(Term{false, nullptr, sums, (float)(-lw * tp.t->dd_weight), win});
+        }
         STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
         return STX_OK;
     };
@@ -1188,7 +1205,10 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     };
     auto fusable = [&](size_t k) {
         int ns = 0, nc = 0;
-        for (const Term &t : terms[k]) (t.style ? ns : nc)++;
+        for (const Term &t : terms[k]) {
+            if (!t.style && !t.src) return false;      // Deep-Dream terms take the stand-alone path
+            (t.style ? ns : nc)++;
+        }
         return ns <= 1 && nc <= 1;
     };
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void content_sums_kernel(const float *__restri
         const int x = i % w.fw;
         const int y = (i / w.fw) % w.fh;
         const int c = i / ((size_t)w.fw * w.fh);
-        const float d = feat[i] - content[content_index(w, c, y, x)];
+        const float d = feat[i] - (content ? content[content_index(w, c, y, x)] : 0.f);   // null map: Deep Dream
         sq += d * d;
         ab += fabsf(d);
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__
         const int x = i % w.fw;
         const int y = (i / w.fw) % w.fh;
         const int c = i / ((size_t)w.fw * w.fh);
-        const float v = scale * (feat[i] - content[content_index(w, c, y, x)]);
+        const float v = scale * (feat[i] - (content ? content[content_index(w, c, y, x)] : 0.f));
         diff[i] = ACC ? diff[i] + v : v;
     }
 }

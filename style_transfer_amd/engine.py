@@ -278,8 +278,9 @@ class TileEngine:
                  float(init_divisor))
 
     # --------------------------------------------------------------------------- SCGradRequest
-    def _taps(self, content_layers, style_layers, layer_weights, content_weight, style_weight):
-        names = list(dict.fromkeys(list(content_layers) + list(style_layers)))
+    def _taps(self, content_layers, style_layers, layer_weights, content_weight, style_weight,
+              dd_layers=(), dd_weight=None):
+        names = list(dict.fromkeys(list(content_layers) + list(style_layers) + list(dd_layers)))
         taps = (lib.Tap * len(names))()
         for t, name in zip(taps, names):
             t.layer = self._cstr(name)
@@ -288,10 +289,13 @@ class TileEngine:
             t.content_weight = float(content_weight.get(name, 0.0)) if t.is_content else 0.0
             t.is_style = int(name in style_layers)
             t.style_weight = float(style_weight.get(name, 0.0)) if t.is_style else 0.0
+            t.is_dd = int(name in dd_layers)
+            t.dd_weight = float(dd_weight.get(name, 0.0)) if t.is_dd and dd_weight else 0.0
         return taps, len(names)
 
     def sc_grad_tile_async(self, img, start, roll, content_layers, style_layers, layer_weights,
-                           content_weight, style_weight, grad_out=None):
+                           content_weight, style_weight, grad_out=None, dd_layers=(),
+                           dd_weight=None):
         """Enqueues one tile evaluation; returns a PendingTile (read it after ``sync()``)."""
         ptr, mem, keep = _as_arg(img)
         th, tw = keep.shape[-2:]
@@ -300,7 +304,7 @@ class TileEngine:
         gptr, gmem, gkeep = (grad_out.ptr, lib.DEVICE, grad_out) \
             if isinstance(grad_out, DeviceArray) else (grad_out.ctypes.data, lib.HOST, grad_out)
         taps, n_taps = self._taps(content_layers, style_layers, layer_weights, content_weight,
-                                  style_weight)
+                                  style_weight, dd_layers, dd_weight)
         roll_c = (ctypes.c_int * 2)(int(roll[0]), int(roll[1])) if roll is not None \
             else (ctypes.c_int * 2)(0, 0)
         start_c = (ctypes.c_int * 2)(int(start[0]), int(start[1]))
@@ -310,11 +314,12 @@ class TileEngine:
         return pending
 
     def sc_grad_tile(self, img, start, roll, content_layers, style_layers, layer_weights,
-                     content_weight, style_weight):
+                     content_weight, style_weight, dd_layers=(), dd_weight=None):
         """(loss, grad[3,th,tw]) of one tile -- CaffeModel.eval_sc_grad_tile with the worker's
         content roll (style_transfer.py:230-241,556-612)."""
         pending = self.sc_grad_tile_async(img, start, roll, content_layers, style_layers,
-                                          layer_weights, content_weight, style_weight)
+                                          layer_weights, content_weight, style_weight,
+                                          dd_layers=dd_layers, dd_weight=dd_weight)
         self.sync()
         return pending.loss, pending.grad
 

@@ -159,12 +159,14 @@ class TileFarm:
                 self._roll_host(f, -xy * 32 // self.layer_info(layer)[0])
         return feats
 
-    def prepare_features_device(self, img, layers, tile_size=512, passes=10):
+    def prepare_features_device(self, img, layers, tile_size=512, passes=10, roll=None):
         """prepare_features with everything on the master GPU: the image is uploaded once, tiles
         are cut with the roll as an index offset, tile maps are stitched by stx_map_place and a
         pass is folded into the average by stx_map_roll_add (acc += roll(feats, -shift) / passes,
         which is the reference's roll-accumulate-unroll of the accumulator, bit for bit).
-        Returns {layer: DeviceArray}.  Same RNG draws as the reference."""
+        Returns {layer: DeviceArray}.  Same RNG draws as the reference.  ``roll``: the maps of
+        roll2(img, roll) instead (preprocess_images(..., roll=xy) of the reference's --jitter
+        mode, style_transfer.py:789-794); the result stays in that rolled frame."""
         eng = self.master
         img = np.ascontiguousarray(img, np.float32)
         hw = np.array(img.shape[-2:])
@@ -189,13 +191,14 @@ class TileFarm:
             if i > 0:
                 xy = np.int32(np.random.uniform(size=2) * hw) // 32
             shift = xy * 32
+            cut_shift = shift if roll is None else shift + np.asarray(roll, np.int64)
             for rect in rects:
                 th, tw = rect[1] - rect[0], rect[3] - rect[2]
                 if (th, tw) not in tiles:
                     tiles[(th, tw)] = eng.empty((3, th, tw))
                     tile_feats[(th, tw)] = {}
                 tile = tiles[(th, tw)]
-                image_ops.cut_tile(eng, d_img, shift, rect, tile)
+                image_ops.cut_tile(eng, d_img, cut_shift, rect, tile)
                 feats = eng.features_tile_device(tile, list(layers), tile_feats[(th, tw)])
                 for layer in layers:
                     scale, _ = self.layer_info(layer)
@@ -238,12 +241,18 @@ class TileFarm:
         return self._staging[key]
 
     def eval_sc_grad(self, img, grad, roll, content_layers, style_layers, layer_weights,
-                     content_weight, style_weight, tile_size):
+                     content_weight, style_weight, tile_size, dd_layers=(), dd_weight=None,
+                     content_roll=None):
         """Summed loss and stitched gradient of all tiles (style_transfer.py:614-645).
 
         img, grad: DeviceArray [3,H,W] on the master GPU, both in the UN-rolled frame; ``roll`` is
         the current iteration's shift in pixels (what the reference passes as the request's
-        ``roll`` after physically rolling the image by it).  Returns the loss."""
+        ``roll`` after physically rolling the image by it).  ``content_roll`` (default: ``roll``)
+        is the shift the engines apply to their content maps; --jitter hands them maps that
+        are already in the rolled frame and passes (0, 0) (style_transfer.py:789-798).
+        Returns the loss."""
+        if content_roll is None:
+            content_roll = roll
         rects = tile_grid(img.shape[-2:], tile_size)
         engines = self._engines_for(len(rects))
         n = len(engines)
@@ -274,8 +283,9 @@ class TileFarm:
             if stage is not None:
                 tile.copy_from(stage[0])            # peer copy on the worker's stream
             pending.append(eng.sc_grad_tile_async(
-                tile, (rect[0], rect[2]), roll, content_layers, style_layers, layer_weights,
-                content_weight, style_weight, grad_out=tgrad))
+                tile, (rect[0], rect[2]), content_roll, content_layers, style_layers,
+                layer_weights, content_weight, style_weight, grad_out=tgrad,
+                dd_layers=dd_layers, dd_weight=dd_weight))
         for eng in engines[1:]:
             eng.sync()
         for (ei, rect, tile, tgrad, stage) in jobs:

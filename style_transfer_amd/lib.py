@@ -48,7 +48,8 @@ class StyleTarget(ctypes.Structure):
 class Tap(ctypes.Structure):
     _fields_ = [('layer', ctypes.c_char_p), ('layer_weight', ctypes.c_double),
                 ('is_content', ctypes.c_int), ('content_weight', ctypes.c_double),
-                ('is_style', ctypes.c_int), ('style_weight', ctypes.c_double)]
+                ('is_style', ctypes.c_int), ('style_weight', ctypes.c_double),
+                ('is_dd', ctypes.c_int), ('dd_weight', ctypes.c_double)]
 
 
 # name -> argtypes; every function returns int status except the three noted below.

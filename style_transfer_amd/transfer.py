@@ -141,7 +141,7 @@ class StyleTransfer:
         self.current_raw = None     # DeviceArray: averaged iterate of the last step
         self.step = 0
         self.step_times = []
-        for name in ('swt_weight', 'dd_weight', 'jitter'):
+        for name in ('swt_weight',):
             # lazy (callable) values could turn non-zero mid-run: refuse them outright
             raw = getattr(getattr(args, 'ns', args), name, 0)
             if callable(raw) or raw:
@@ -180,39 +180,53 @@ class StyleTransfer:
             if last:
                 return
 
-    def preprocess_images(self, content_images, style_images, content_layers, style_layers):
+    def preprocess_images(self, content_images, style_images, content_layers, style_layers,
+                          roll=None):
         """Targets of one scale: the style Grams, averaged with equal weight over every style
         image and ladder size, and the tiling-averaged content features
-        (style_transfer.py:488-554).  Everything stays on the master GPU."""
+        (style_transfer.py:488-554).  Everything stays on the master GPU.  ``roll`` (--jitter,
+        once per iteration): features of the pictures rolled by it, one pass, no messages."""
         farm, tile = self.farm, self.args.tile_size
-        print('Preprocessing the style image(s)...')
+        if roll is None:
+            print('Preprocessing the style image(s)...')
         if not self.styles:
             total, count = {}, 0
             for index, image in enumerate(style_images):
                 for variant in self._style_variants(index, image):
                     feats = farm.prepare_features_device(self.pil_to_image(variant), style_layers,
-                                                         tile, passes=1)
+                                                         tile, passes=1, roll=roll)
                     for layer, feat in feats.items():
                         gram = farm.gram_matrix(feat)
                         feat.free()
                         total[layer] = gram if layer not in total else total[layer] + gram
                     count += 1
             self.styles.append({layer: gram / count for layer, gram in total.items()})
-        print('Preprocessing the content image(s)...')
+        if roll is None:
+            print('Preprocessing the content image(s)...')
         self.contents += [farm.prepare_features_device(self.pil_to_image(image), content_layers,
-                                                       tile, passes=10)
+                                                       tile, passes=10 if roll is None else 1,
+                                                       roll=roll)
                           for image in content_images]
+
+    def _drop_contents(self):
+        for content in self.contents:
+            for feat in content.values():
+                if hasattr(feat, 'free'):
+                    feat.free()
+        self.contents = []
 
     # ------------------------------------------------------------------------------ objective
     def eval_loss_and_grad(self, params, sc_args):
         """Loss and gradient of the full image (style_transfer.py:700-736).  ``params`` is the
         device iterate; returns (loss, device gradient)."""
         args = self.args
-        roll, content_layers, style_layers, content_weight, style_weight = sc_args
+        (roll, content_layers, style_layers, content_weight, style_weight, dd_layers, dd_weight,
+         content_roll) = sc_args
         lw = self.layer_weights['data']
         loss = self.farm.eval_sc_grad(params, self.grad, roll, content_layers, style_layers,
                                       self.layer_weights, content_weight, style_weight,
-                                      args.tile_size)
+                                      args.tile_size, dd_layers=dd_layers, dd_weight=dd_weight,
+                                      content_roll=content_roll)
         aux_on = self.aux_image is not None
         if args.tv_weight or args.p_weight or aux_on:
             reg = image_ops.regularizers(
@@ -234,14 +248,15 @@ class StyleTransfer:
 
         content_layers, content_weight = parse_weights(args.content_layers, args.content_weight)
         style_layers, style_weight = parse_weights(args.style_layers, 1)
-        for content in self.contents:          # device-resident maps of the previous scale
-            for feat in content.values():
-                if hasattr(feat, 'free'):
-                    feat.free()
-        self.contents = []
+        dd_layers, dd_weight = parse_weights(args.dd_layers, args.dd_weight)
+        jitter = bool(args.jitter)
+        self._drop_contents()                  # device-resident maps of the previous scale
         if not args.style_multiscale:
             self.styles = []
-        self.preprocess_images(content_images, style_images, content_layers, style_layers)
+        # --jitter: the content maps are recomputed every iteration from the shifted picture
+        # (style_transfer.py:757-763,789-794), only the style targets are fixed per scale
+        self.preprocess_images([] if jitter else content_images, style_images,
+                               [] if jitter else content_layers, style_layers)
         self.farm.set_contents_and_styles(self.contents, self.styles)
 
         if self.grad is None or self.grad.shape != self.img.shape:
@@ -261,10 +276,20 @@ class StyleTransfer:
             state.step = step - 1
             # the iteration's random shift (style_transfer.py:777-786); the reference rolls the
             # image and the optimizer state by xy * jitter_scale, here it is an index offset
-            xy = np.int32(np.random.uniform(-0.5, 0.5, size=2) * img_size) // jitter_scale
-            roll = xy * jitter_scale
+            scale = 1 if jitter else jitter_scale
+            xy = np.int32(np.random.uniform(-0.5, 0.5, size=2) * img_size) // scale
+            roll = xy * scale
             self.optimizer.roll(roll)
-            sc_args = (roll, content_layers, style_layers, content_weight, style_weight)
+            content_roll = None
+            if jitter:
+                # any pixel shift; the engines get content maps of the shifted picture and leave
+                # them where they are
+                self._drop_contents()
+                self.preprocess_images(content_images, [], content_layers, [], roll=roll)
+                self.farm.set_contents_and_styles(self.contents, self.styles)
+                content_roll = (0, 0)
+            sc_args = (roll, content_layers, style_layers, content_weight, style_weight,
+                       dd_layers, dd_weight, content_roll)
             avg_img, loss = self.optimizer.update(lambda p: self.eval_loss_and_grad(p, sc_args))
             self.optimizer.roll(-roll)
             update_size, tv_loss = image_ops.step_stats(self.engine, avg_img, self.old_avg)

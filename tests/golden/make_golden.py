@@ -217,6 +217,15 @@ def main():
             content_weight, style_weight, {})
         out[tag + 'single/loss'] = np.float64(tloss)
         out[tag + 'single/grad'] = tgrad.copy()
+        # the same tile with a Deep-Dream term on two layers (style_transfer.py:602-604)
+        dd_layers, dd_weight = st.StyleTransfer.parse_weights(['conv4_3', 'conv2_2:3'], 0.04)
+        dlayers = [l for l in reversed(master.layers())
+                   if l in content_layers + style_layers + dd_layers]
+        dloss, dgrad = worker_model.eval_sc_grad_tile(
+            tile, np.array([8, 16]), dlayers, content_layers, style_layers, dd_layers,
+            layer_weights, content_weight, style_weight, dd_weight)
+        out[tag + 'dream/loss'] = np.float64(dloss)
+        out[tag + 'dream/grad'] = dgrad.copy()
         feats = worker_model.eval_features_tile(tile, ['conv1_1', 'pool1', 'conv5_1'])
         out[tag + 'single/feat_conv5_1'] = feats['conv5_1'].copy()
         out[tag + 'single/feat_pool1_sum'] = np.float64(feats['pool1'].sum(dtype=np.float64))
@@ -400,6 +409,30 @@ def main():
     out['e2e_aux/argv'] = np.array(' '.join(sys.argv[1:]))
     out['e2e_aux/log'] = np.float64(log)
     out['e2e_aux/final_raw'] = transfer.current_raw.copy()
+
+    # ------- 4f. --jitter (content maps recomputed every iteration from the shifted picture,
+    # any pixel shift: style_transfer.py:757-763,780-794) together with a Deep-Dream term
+    # (style_transfer.py:602-604).  One scale, 2 x 2 tiles, three Adam steps.
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png', '--jitter', '--dd-weight',
+                '0.02', '--dd-layers', 'conv4_3', 'conv3_2:2', '--size', '80', '--min-size', '80',
+                '--tile-size', '48', '--iterations', '3', '--display', 'none', '--seed', '31']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(80, 72, 80)
+    style_u8 = smooth_image(81, 56, 64)
+    log = []
+    np.random.seed(st.ARGS.seed)
+    transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                 None, None, callback=Cb())
+    out['e2e_jitter/content_u8'], out['e2e_jitter/style_u8'] = content_u8, style_u8
+    out['e2e_jitter/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e_jitter/log'] = np.float64(log)
+    out['e2e_jitter/final_raw'] = transfer.current_raw.copy()
 
     # ----------- 4d. the six deploy prototxts the reference ships, as parsed layer tuples (data
     # for the --model reader): (name, type, bottom, top, num_output, pad, kernel,

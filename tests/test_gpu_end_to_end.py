@@ -195,3 +195,30 @@ def test_aux_image_term_matches_reference_run(golden):
                                                       np.percentile(diff, 99.9)))
     assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
     farm.close()
+
+
+def test_jitter_and_deep_dream_run_matches_reference(golden):
+    """--jitter (content maps recomputed every iteration from the shifted picture, any pixel shift:
+    style_transfer.py:757-763,780-794) with --dd-weight / --dd-layers, against the reference's
+    own transfer_multiscale run."""
+    from argparse import Namespace
+    argv = str(golden['e2e_jitter.argv']).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net(args.model)
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e_jitter.content_u8'])],
+                           [Image.fromarray(golden['e2e_jitter.style_u8'])],
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    ref, got = golden['e2e_jitter.log'], np.float64(log)
+    print(got[:, 2] / ref[:, 2] - 1)
+    assert got.shape == ref.shape
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=3e-4), (got[:, 2], ref[:, 2])
+    diff = np.abs(st.current_raw.get() - golden['e2e_jitter.final_raw'])
+    print('jitter run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
+    assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
+    farm.close()

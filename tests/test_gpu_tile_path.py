@@ -135,3 +135,28 @@ def test_errors_are_reported_not_fatal():
     eng.set_contents_and_styles([], [])
     with pytest.raises(StxError):
         eng.sc_grad_tile(tile, (0, 0), (0, 0), ['conv4_2'], [], {}, {'conv4_2': 1.0}, {})
+
+
+@pytest.mark.parametrize('tag,model', [('vgg19', 'vgg19'), ('vgg16avg', 'vgg16_avgpool')])
+def test_deep_dream_term_matches_reference_vectors(golden, tag, model):
+    """dd_layers / dd_weight (style_transfer.py:602-604): loss -= lw*dd*1/2|F|^2 and
+    diff -= lw*dd*normalize(F) on two layers, against the reference's own eval_sc_grad_tile."""
+    g, om, (cl, cw, sl, sw) = _targets(golden, tag, model)
+    eng = gpu_engine(model)
+    eng.set_contents_and_styles(om.contents, om.styles)
+    lw = {'conv3_1': float(g['lw_conv3_1'])}
+    dl, dw = ['conv4_3', 'conv2_2'], {'conv4_3': 0.01, 'conv2_2': 0.03}     # parse_weights(.., 0.04)
+    tile = np.ascontiguousarray(g['img_rolled'][:, 8:48, 16:72])
+    loss, grad = eng.sc_grad_tile(tile, (8, 16), (0, 0), cl, sl, lw, cw, sw, dd_layers=dl,
+                                  dd_weight=dw)
+    assert loss == pytest.approx(float(g['dream.loss']), rel=TIGHT)
+    ref_loss, ref_grad = om.sc_grad_tile(tile, (8, 16), cl, sl, lw, cw, sw, dd_layers=dl, dd_weight=dw)
+    assert ref_loss == pytest.approx(float(g['dream.loss']), rel=TIGHT)        # oracle == reference
+    assert max_rel(ref_grad, g['dream.grad']) < TIGHT
+    if 'avg' in model:
+        assert max_rel(grad, g['dream.grad']) < TIGHT
+    else:
+        assert l2_rel(grad, g['dream.grad']) < FLIP_L2
+    # the term really is there: without it the loss is the plain fixture's
+    plain, _ = eng.sc_grad_tile(tile, (8, 16), (0, 0), cl, sl, lw, cw, sw)
+    assert plain == pytest.approx(float(g['single.loss']), rel=TIGHT) and plain != loss
