@@ -1173,7 +1173,8 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
         return STX_OK;
     };
-    const bool interleave = e->side == e->stream;
+    // (STX_TERMS_LATE=1: all loss terms after the forward pass, for A/B measurements)
+    const bool interleave = e->side == e->stream && !(getenv("STX_TERMS_LATE") && atoi(getenv("STX_TERMS_LATE")));
     const std::function<int(int)> hook = [&](int blob) -> int {
         const int k = tap_of[blob];
         return k >= 0 ? launch_terms((size_t)k) : STX_OK;
