@@ -1,5 +1,9 @@
+"""--aux-image: the reference rolls the image, not the auxiliary image.  Runs the reference's
+fixture (tests/golden, e2e_aux) with the shift passed to the regularizer kernel and without it
+and prints the loss error of both (measured: 1.4e-4 vs 4.3e-3, final image 8.5 vs 55)."""
 import sys, os
-sys.path.insert(0, '/root/repo')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 import numpy as np
 from argparse import Namespace
 from PIL import Image
@@ -9,7 +13,7 @@ from style_transfer_amd.netspec import builtin_net
 from style_transfer_amd.transfer import StyleTransfer
 from style_transfer_amd.weights import synthetic_weights
 from style_transfer_amd import image_ops
-z = np.load('/root/repo/tests/golden/reference_vectors.npz')
+z = np.load(os.path.join(REPO, 'tests', 'golden', 'reference_vectors.npz'))
 golden = {k: z[k] for k in z.files}
 orig = image_ops.regularizers
 for mode in ('rolled', 'unrolled'):
