@@ -418,17 +418,6 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     run_chunk(cur, chunk, no{}, no{});
     __syncthreads();
 
-    // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
-    float2 *ex = reinterpret_cast<float2 *>(lds);     // [wave][i*16 + r][lane], 128 KB in all
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float c0 = acc[i][0][r], c1 = acc[i][1][r], c2 = acc[i][2][r], c3 = acc[i][3][r];
-            ex[(wave * 32 + i * 16 + r) * 64 + lane] = make_float2(c0 + c1 + c2, c1 - c2 - c3);
-        }
-    __syncthreads();
-
     float s_scale = 0.f, c_scale = 0.f;
     if (EPI == kEpiDgradInject) {
         const float n = (float)((size_t)a.M * HW);
@@ -440,50 +429,67 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int yy = y0 + 2 * (trow * TYW + l31 / TXW), xx0 = x0 + 2 * (l31 % TXW);
     // this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel blocks: D register
     // r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half
-    if (vec2) {
-        // Even rows: sixteen aligned float2 outputs per lane.  Everything the epilogue reads
-        // (ReLU mask, style / content terms, bias) is fetched for all sixteen first, from
-        // clamped addresses so that no load sits behind a branch: with the loads inside the
-        // per-output code each output waited for its own round trips to memory and the
-        // epilogue of the shallow layers took longer than their main loop.
-        long idx[16];
-        bool ok[16];
-        int mm[16];
+    // Everything the epilogue reads (ReLU mask, style / content terms, bias) is requested before
+    // the exchange of the transform rows through LDS, for all sixteen outputs of the lane, from
+    // clamped addresses so that no load sits behind a branch; the values land during the
+    // exchange.  (Requested ahead of the last chunk of matrix work they make the compiler spill
+    // around it: measured twice as slow.)
+    long idx[16];
+    bool ok[16];
+    int mm[16];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            const int i = n >> 3, rr = (n >> 1) & 3, y = n & 1;
-            mm[n] = m0 + i * 32 + rr + 8 * xi + 4 * half;
-            ok[n] = yy + y < a.H && xx0 < a.W && mm[n] < a.M;
-            idx[n] = ok[n] ? (long)mm[n] * HW + (yy + y) * a.W + xx0 : 0;
+    for (int n = 0; n < 16; ++n) {
+        const int i = n >> 3, rr = (n >> 1) & 3, y = n & 1;
+        mm[n] = m0 + i * 32 + rr + 8 * xi + 4 * half;
+        ok[n] = yy + y < a.H && xx0 < a.W && mm[n] < a.M;
+        idx[n] = ok[n] ? (long)mm[n] * HW + (yy + y) * a.W + xx0 : 0;
+    }
+    float2 mk[16], sg[16], ft[16], ct[16];
+    float bs[16];
+    if (!vec2) {
+        // odd widths / unaligned arrays: the scalar path below does its own reads
+    } else if (EPI == kEpiForward) {
+        if (a.bias) {
+#pragma unroll
+            for (int n = 0; n < 16; n += 2) bs[n] = bs[n + 1] = a.bias[mm[n] < a.M ? mm[n] : 0];
         }
-        float2 mk[16], sg[16], ft[16], ct[16];
-        float bs[16];
-        if (EPI == kEpiForward) {
-            if (a.bias) {
+    } else if (EPI != kEpiPartial) {
+        if (a.mask) {
 #pragma unroll
-                for (int n = 0; n < 16; n += 2) bs[n] = bs[n + 1] = a.bias[mm[n] < a.M ? mm[n] : 0];
+            for (int n = 0; n < 16; ++n) mk[n] = *reinterpret_cast<const float2 *>(a.mask + idx[n]);
+        }
+        if (EPI == kEpiDgradInject) {
+            if (a.inj.sgrad) {
+#pragma unroll
+                for (int n = 0; n < 16; ++n)
+                    sg[n] = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx[n]);
             }
-        } else if (EPI != kEpiPartial) {
-            if (a.mask) {
+        }
+    }
+
+    // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
+    float2 *ex = reinterpret_cast<float2 *>(lds);     // [wave][i*16 + r][lane], 128 KB in all
 #pragma unroll
-                for (int n = 0; n < 16; ++n) mk[n] = *reinterpret_cast<const float2 *>(a.mask + idx[n]);
-            }
-            if (EPI == kEpiDgradInject) {
-                if (a.inj.sgrad) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int n = 0; n < 16; ++n)
-                        sg[n] = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx[n]);
-                }
-                if (a.inj.content) {
+        for (int r = 0; r < 16; ++r) {
+            const float c0 = acc[i][0][r], c1 = acc[i][1][r], c2 = acc[i][2][r], c3 = acc[i][3][r];
+            ex[(wave * 32 + i * 16 + r) * 64 + lane] = make_float2(c0 + c1 + c2, c1 - c2 - c3);
+        }
+    __syncthreads();
+
+    if (vec2) {
+        // Even rows: sixteen aligned float2 outputs per lane (mask and style term were requested
+        // ahead of the exchange, see above; the content term, one layer per tile evaluation,
+        // is read here, when the accumulators no longer occupy registers).
+        if (EPI == kEpiDgradInject && a.inj.content) {
 #pragma unroll
-                    for (int n = 0; n < 16; ++n) {
-                        ft[n] = *reinterpret_cast<const float2 *>(a.inj.feat + idx[n]);
-                        const int cy = ok[n] ? yy + (n & 1) : 0, cx = ok[n] ? xx0 : 0;
-                        const int cm = ok[n] ? mm[n] : 0;
-                        ct[n].x = a.inj.content[content_index(a.inj.win, cm, cy, cx)];
-                        ct[n].y = a.inj.content[content_index(a.inj.win, cm, cy, cx + 1 < a.W ? cx + 1 : cx)];
-                    }
-                }
+            for (int n = 0; n < 16; ++n) {
+                ft[n] = *reinterpret_cast<const float2 *>(a.inj.feat + idx[n]);
+                const int cy = ok[n] ? yy + (n & 1) : 0, cx = ok[n] ? xx0 : 0;
+                const int cm = ok[n] ? mm[n] : 0;
+                ct[n].x = a.inj.content[content_index(a.inj.win, cm, cy, cx)];
+                ct[n].y = a.inj.content[content_index(a.inj.win, cm, cy, cx + 1 < a.W ? cx + 1 : cx)];
             }
         }
 #pragma unroll
