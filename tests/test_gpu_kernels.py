@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 CONV_CASES = [  # (Cin, Cout, H, W): SURVEY section 8c list + shapes that hit every tile config
     (3, 64, 33, 47), (64, 64, 32, 32), (256, 512, 9, 11), (64, 128, 70, 65), (128, 256, 40, 40),
     (512, 512, 16, 16), (64, 3, 37, 50), (128, 64, 24, 72), (20, 36, 19, 31), (16, 70, 13, 200),
-    (72, 40, 130, 129)]
+    (72, 40, 130, 129),
+    # degenerate planes and ragged channel counts (partial chunks, partial channel tiles)
+    (8, 33, 1, 1), (9, 65, 2, 3), (24, 96, 5, 67), (130, 66, 31, 33)]
 # every convolution kernel family on every shape it accepts; None = the engine's own choice
 CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino4a', 'wino4b', 'wino4c']
 
