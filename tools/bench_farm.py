@@ -11,7 +11,8 @@ from style_transfer_amd.weights import synthetic_weights
 size = int(sys.argv[1]); tile = int(sys.argv[2]); devices = [int(d) for d in sys.argv[3].split(',')]
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 net = builtin_net('vgg19')
-farm = TileFarm(net, devices, synthetic_weights(net, 0), verbose=False)
+farm = TileFarm(net, devices, synthetic_weights(net, 0), verbose=False,
+                streams_per_device=int(os.environ.get('STREAMS', '4')))
 eng = farm.master
 rng = np.random.RandomState(0)
 cl, sl = ['conv4_2'], ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
