@@ -38,6 +38,10 @@
 #define STX_ABLATE_V 0
 #endif
 
+#ifndef STX_W2_BURST
+#define STX_W2_BURST 1
+#endif
+
 #ifndef STX_W2_SKIP
 #define STX_W2_SKIP 0   // timing experiments (tools/ubench/wino2_bench.hip): 1 no filter loads, 2 no patch
 #endif                 // loads in the main loop.  Wrong results when non-zero.
@@ -73,6 +77,19 @@ constexpr int STAGE = U_FLOATS + V_FLOATS;    // 64 KB
 constexpr size_t kLdsBytes = 2 * STAGE * sizeof(float);
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// LDS traffic of this wave complete, then the workgroup barrier.  Unlike __syncthreads() this does
+// not wait for the global loads in flight for the chunk after next (vmcnt is left alone).
+#ifndef STX_W2_LDSBAR
+#define STX_W2_LDSBAR 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if STX_W2_LDSBAR
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 
 // The shared tail of every output pair: (m, yy, xx0) and (m, yy, xx0 + 1).
 template <int EPI>
@@ -353,10 +370,24 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                     }
                     if (STORE) {
                         if (p < 4) u_write(p, ldsb);
+#if STX_W2_BURST
+                        // Bt d B as ONE burst of vector work: an isolated vector instruction
+                        // between two MFMAs costs the matrix pipe ~13 cycles, the members of a
+                        // burst ~4 each (tools/ubench/solo_issue.hip)
+                        if (p == 8) fix_edges();
+                        if (p == 9) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) row_op(q);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) col_op(q);
+                        }
+                        if (p >= 10 && p < 14) v_write(p - 10, ldsb);
+#else
                         if (p == 8) fix_edges();
                         if (p >= 8 && p < 16) row_op(p - 8);
                         if (p >= 20 && p < 28) col_op(p - 20);
                         if (p >= 28) v_write(p - 28, ldsb);
+#endif
                     }
                     if (LOAD && !(STX_W2_SKIP & 1)) {
                         if (p >= 4 && p < 8) u_load(p - 4, ws);
@@ -396,27 +427,27 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     for (; chunk + 3 < c_end; chunk += 2) {
         STX_T(t0);
         run_chunk(0, chunk, yes{}, yes{});
-        __syncthreads();
+        lds_barrier();
         run_chunk(1, chunk + 1, yes{}, yes{});
         STX_T(t1);
-        __syncthreads();
+        lds_barrier();
         STX_T(t2);
         t_work += t1 - t0, t_barrier += t2 - t1;
     }
     for (; chunk + 2 < c_end; ++chunk) {
         run_chunk(cur, chunk, yes{}, yes{});
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     }
     STX_T(t_main_end);
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
         ++chunk;
     }
     run_chunk(cur, chunk, no{}, no{});
-    __syncthreads();
+    lds_barrier();
 
     float s_scale = 0.f, c_scale = 0.f;
     if (EPI == kEpiDgradInject) {

@@ -333,7 +333,18 @@ static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, Co
         if (!strcmp(algo, "wino1")) { *out = wino_config_by_id(M >= 64 ? 0 : 1); return true; }
     }
     if (!e->winograd) return false;
-    *out = M > 32 ? wino4_config(wino4_pick_geometry(K, M, H, W)) : wino_config_by_id(1);
+    if (M <= 32) {
+        *out = wino_config_by_id(1);
+        return true;
+    }
+    // Two kernels with identical arithmetic (bit-identical results).  The eight-wave one is a
+    // percent or two faster on the even, power-of-two-ish planes of the benchmark tile and has
+    // the registers to request everything a loss-injecting epilogue reads at once; the four-wave
+    // one has a third patch geometry chosen by a cost model and a branch-free path for odd
+    // widths (measured on the planes of 724- and 362-pixel tiles: 0.211 -> 0.200 ms at 181 x 181,
+    // 0.077 -> 0.062 at 46 x 46).  Shape only, never timing.
+    const int g4 = wino4_pick_geometry(K, M, H, W), g2 = wino2_pick_geometry(H, W);
+    *out = ((W & 1) || g4 != g2) ? wino4_config(g4) : wino2_config(g2);
     return true;
 }
 
@@ -480,12 +491,6 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 1, p, &cfg));   // tuned without the injection terms
-    // The loss-injecting epilogue reads two more arrays of the output's size (ReLU mask, style
-    // term).  The eight-wave kernel spreads those reads over twice the threads and requests them
-    // all at once; the four-wave kernel has to fetch them in four dependent round trips (measured
-    // 0.70 vs 0.44 ms on conv1_2's backward), so the injecting layers stay on the eight-wave one.
-    // Same arithmetic, same results.
-    if (inj && cfg.id >= 210 && !getenv("STX_CONV_ALGO")) cfg = wino2_config(wino2_pick_geometry(p.H, p.W));
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
