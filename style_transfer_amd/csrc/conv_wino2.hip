@@ -254,21 +254,22 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         // differences right behind the loads, with a vmcnt wait in the wrong place.
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xreg[i]));
-        if (corner) {
-            asm volatile("");      // keeps this a (scalar) branch: one wave in the whole launch takes it
-            // plain floats: element assignments through a select turn into dynamic indexing
-            const float r0 = xreg[1].x, r1 = xreg[1].y, r2 = xreg[1].z, r3 = xreg[1].w;
-            xreg[1].y = corner_lane ? r0 : r1;
-            xreg[1].z = corner_lane ? r1 : r2;
-            xreg[1].w = corner_lane ? r2 : r3;
-        }
-        if (edge_l) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xreg[i].x = left ? 0.f : xreg[i].x;
-        }
-        if (edge_r) {
+        // ONE uniform branch (workgroups on the left / right border of the plane), issued right
+        // behind an MFMA so that the instruction-fetch bubble of the jump falls into its shadow;
+        // inside, the selects are unconditional
+        if (edge_l || edge_r) {
+            asm volatile("");      // keeps this a (scalar) branch
+            if (corner) {
+                asm volatile("");  // one wave in the whole launch takes it
+                // plain floats: element assignments through a select turn into dynamic indexing
+                const float r0 = xreg[1].x, r1 = xreg[1].y, r2 = xreg[1].z, r3 = xreg[1].w;
+                xreg[1].y = corner_lane ? r0 : r1;
+                xreg[1].z = corner_lane ? r1 : r2;
+                xreg[1].w = corner_lane ? r2 : r3;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                xreg[i].x = left ? 0.f : xreg[i].x;
                 xreg[i].z = ok2 ? xreg[i].z : 0.f;
                 xreg[i].w = ok3 ? xreg[i].w : 0.f;
             }
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // chunk into the other buffer and (LOAD) the loads of the chunk after that dealt out between
     // the MFMAs: pieces 0-3 filter-bank writes, 4-7 filter-bank loads, 8-15 row adds, 16-19 patch
     // loads, 20-27 column adds, 28-31 patch writes.  sched_barrier pins the order.
+    f32x4 av[2][2], bv[2];
     auto run_chunk = [&](int cur, int chunk, auto store_c, auto load_c) {
         constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
         const float *base = lds + cur * STAGE;
@@ -347,10 +349,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             ws = (unsigned)sgpr((int)(w_base + (unsigned)(chunk + 2) * w_chunk));
             xs = (unsigned)sgpr((int)((unsigned)(chunk + 2) * x_chunk));
         }
-        f32x4 av[2][2], bv[2];
-        av[0][0] = *reinterpret_cast<const f32x4 *>(base + a_off);
-        av[0][1] = *reinterpret_cast<const f32x4 *>(base + a_off + 32 * 4);
-        bv[0] = *reinterpret_cast<const f32x4 *>(base + b_off);
+        const float *next = lds + (cur ^ 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -358,15 +357,24 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int m = c * 2 + i, p = s * 8 + m;
+                    if (STORE && p == 24) {
+                        // every wave has written its share of the next chunk (pieces < 14) and
+                        // issued its last reads of this one (during k-step 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds_barrier();
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i][c], bv[s & 1][c],
                                                                       acc[i][c], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (s + 1 < NS && m < 3) {      // operands of the next k-step
-                        const int o = (2 * (s + 1)) * 64 * 4;       // BM == 64 tiles: same stride
-                        if (m == 0) av[(s + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(base + a_off + o);
-                        if (m == 1) av[(s + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(base + a_off + o + 32 * 4);
-                        if (m == 2) bv[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(base + b_off + o);
+                    if (m < 3 && (s + 1 < NS || STORE)) {
+                        // operands of the next k-step -- after the last one, of the next chunk's
+                        // first, out of the other buffer (behind the barrier above)
+                        const float *src = s + 1 < NS ? base : next;
+                        const int o = s + 1 < NS ? (2 * (s + 1)) * 64 * 4 : 0;   // BM == 64 tiles: same stride
+                        if (m == 0) av[(s + 1) & 1][0] = *reinterpret_cast<const f32x4 *>(src + a_off + o);
+                        if (m == 1) av[(s + 1) & 1][1] = *reinterpret_cast<const f32x4 *>(src + a_off + o + 32 * 4);
+                        if (m == 2) bv[(s + 1) & 1] = *reinterpret_cast<const f32x4 *>(src + b_off + o);
                     }
                     if (STORE) {
                         if (p < 4) u_write(p, ldsb);
@@ -424,25 +432,28 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     STX_T(t_begin);
     // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
     // of the hand-over and of the operand reads is a register plus an immediate
+    // k-step 0 operands of the first chunk; from then on every chunk leaves those of its
+    // successor behind (the hand-over barrier sits inside the chunk, before k-step 3)
+    {
+        const float *base = lds;
+        av[0][0] = *reinterpret_cast<const f32x4 *>(base + a_off);
+        av[0][1] = *reinterpret_cast<const f32x4 *>(base + a_off + 32 * 4);
+        bv[0] = *reinterpret_cast<const f32x4 *>(base + b_off);
+    }
     for (; chunk + 3 < c_end; chunk += 2) {
         STX_T(t0);
         run_chunk(0, chunk, yes{}, yes{});
-        lds_barrier();
         run_chunk(1, chunk + 1, yes{}, yes{});
         STX_T(t1);
-        lds_barrier();
-        STX_T(t2);
-        t_work += t1 - t0, t_barrier += t2 - t1;
+        t_work += t1 - t0;
     }
     for (; chunk + 2 < c_end; ++chunk) {
         run_chunk(cur, chunk, yes{}, yes{});
-        lds_barrier();
         cur ^= 1;
     }
     STX_T(t_main_end);
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
-        lds_barrier();
         cur ^= 1;
         ++chunk;
     }
