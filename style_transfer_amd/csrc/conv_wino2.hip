@@ -59,6 +59,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
 namespace {
 
@@ -411,6 +412,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     using no = std::integral_constant<bool, false>;
 
     load_stage(c_begin);
+    // clear the accumulators while the first loads are in flight (left alone the compiler sinks the
+    // 128 moves to just before the first MFMA, behind the barrier: ~1000 cycles of an idle pipe)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(acc[i][c]));
     store_stage(0);
     if (c_begin + 1 < c_end) load_stage(c_begin + 1);
     __syncthreads();
@@ -466,127 +473,196 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
         if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
     }
-    const bool vec2 = ((a.W & 1) | (((size_t)a.y | (size_t)a.mask | (size_t)a.inj.feat |
-                                     (size_t)a.inj.sgrad) & 7)) == 0;
+    // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves:
+    //   nu:  (c0 + c1 + c2,  c1 - c2 - c3)          xi:  (p0 + p1 + p2,  p1 - p2 - p3)
+    // After the exchange this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel
+    // blocks (D register r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half) for the 32
+    // tiles of its tile row.  Both stages work on PAIRS of neighbouring registers (two channels)
+    // with v_pk_add_f32, and -- on even plane widths -- everything the epilogue touches in
+    // memory goes through buffer descriptors whose range check does the predication (a lane
+    // outside the plane, or a channel past M, carries an out-of-range offset: loads return 0,
+    // stores are dropped): no divergent branch, no 64-bit address arithmetic, one vector offset
+    // per output row plus one scalar offset per channel.  (The form with pointer arithmetic and
+    // a branch per store issued ~2.5 x as many vector instructions; tools/asm_mix.py.)
+    const bool weven = (a.W & 1) == 0;       // pairs never straddle the end of a row
     const int yy = y0 + 2 * (trow * TYW + l31 / TXW), xx0 = x0 + 2 * (l31 % TXW);
-    // this wave finishes accumulator registers 4*xi .. 4*xi+3 of both channel blocks: D register
-    // r of a block is channel (r & 3) + 8 * (r >> 2) + 4 * half
-    // Everything the epilogue reads (ReLU mask, style / content terms, bias) is requested before
-    // the exchange of the transform rows through LDS, for all sixteen outputs of the lane, from
-    // clamped addresses so that no load sits behind a branch; the values land during the
-    // exchange.  (Requested ahead of the last chunk of matrix work they make the compiler spill
-    // around it: measured twice as slow.)
-    long idx[16];
-    bool ok[16];
-    int mm[16];
+    const unsigned plane_bytes = (unsigned)a.M * (unsigned)HW * 4u;
+    const unsigned HW4 = (unsigned)HW * 4u;
+    unsigned vo[2];                           // first column of the lane's two output rows
+    {
+        const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-        const int i = n >> 3, rr = (n >> 1) & 3, y = n & 1;
-        mm[n] = m0 + i * 32 + rr + 8 * xi + 4 * half;
-        ok[n] = yy + y < a.H && xx0 < a.W && mm[n] < a.M;
-        idx[n] = ok[n] ? (long)mm[n] * HW + (yy + y) * a.W + xx0 : 0;
+        for (int y = 0; y < 2; ++y)
+            vo[y] = (yy + y < a.H && xx0 < a.W) ? lane_base + (unsigned)(y * a.W) * 4u : kOob;
     }
-    float2 mk[16], sg[16], ft[16], ct[16];
-    float bs[16];
-    if (!vec2) {
-        // odd widths / unaligned arrays: the scalar path below does its own reads
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.mask), 0, a.mask ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rft = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
+    const unsigned vpool = (yy < a.H && xx0 < a.W)
+                               ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
+                               : kOob;
+    // channel of output (i, rr) on the lower lane half, clamped to M: a scalar offset must not
+    // exceed the descriptor's range (the check is offset >= num_records - soffset)
+    const int M_ = a.M;
+    auto chan = [&](int i, int rr) __attribute__((always_inline)) {
+        const int c = m0 + i * 32 + rr + 8 * xi;
+        return sgpr(c < M_ ? c : M_);
+    };
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y], so, 0));
+    };
+    auto st2 = [&](int y, unsigned so, f32x2 v) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), ry, vo[y], so, 0);
+    };
+    // The ReLU mask and the style term are requested before the exchange of the transform rows
+    // through LDS, for all sixteen outputs of the lane; the values land during the exchange.
+    // (Requested ahead of the last chunk of matrix work they make the compiler spill around it:
+    // measured twice as slow.)
+    f32x2 mk[16], sg[16];
+    float bs[8];
+    if (!weven) {
+        // odd widths: the scalar path below does its own reads
     } else if (EPI == kEpiForward) {
         if (a.bias) {
 #pragma unroll
-            for (int n = 0; n < 16; n += 2) bs[n] = bs[n + 1] = a.bias[mm[n] < a.M ? mm[n] : 0];
+            for (int n = 0; n < 8; ++n)
+                bs[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rbias, (unsigned)half * 16u,
+                                                      (unsigned)chan(n >> 2, n & 3) * 4u, 0));
         }
     } else if (EPI != kEpiPartial) {
-        if (a.mask) {
 #pragma unroll
-            for (int n = 0; n < 16; ++n) mk[n] = *reinterpret_cast<const float2 *>(a.mask + idx[n]);
-        }
-        if (EPI == kEpiDgradInject) {
-            if (a.inj.sgrad) {
-#pragma unroll
-                for (int n = 0; n < 16; ++n)
-                    sg[n] = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx[n]);
+        for (int n = 0; n < 16; ++n) {
+            const unsigned so = (unsigned)chan(n >> 3, (n >> 1) & 3) * HW4;
+            if (a.mask) mk[n] = ld2(rmask, n & 1, so);
+            if (EPI == kEpiDgradInject) {
+                if (a.inj.sgrad) sg[n] = ld2(rsg, n & 1, so);
             }
         }
     }
 
-    // ---- epilogue.  nu -> two output columns in registers; xi -> two output rows across waves.
-    float2 *ex = reinterpret_cast<float2 *>(lds);     // [wave][i*16 + r][lane], 128 KB in all
+    // exchange: [wave][i][register pair q][lane] x (col 0 of r, col 0 of r + 1, col 1 of r, col 1
+    // of r + 1), 128 KB in all
+    f32x4 *ex = reinterpret_cast<f32x4 *>(lds);
+#define STX_PK_ADD(dst, a_, b_) STX_PK(dst, a_, b_, "")
+#define STX_PK_SUB(dst, a_, b_) STX_PK(dst, a_, b_, "neg_lo:[0,1] neg_hi:[0,1]")
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float c0 = acc[i][0][r], c1 = acc[i][1][r], c2 = acc[i][2][r], c3 = acc[i][3][r];
-            ex[(wave * 32 + i * 16 + r) * 64 + lane] = make_float2(c0 + c1 + c2, c1 - c2 - c3);
+        for (int q = 0; q < 8; ++q) {
+            f32x2 c[4], t, u, o0, o1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = f32x2{acc[i][k][2 * q], acc[i][k][2 * q + 1]};
+            STX_PK_ADD(t, c[0], c[1]);
+            STX_PK_ADD(o0, t, c[2]);
+            STX_PK_SUB(u, c[1], c[2]);
+            STX_PK_SUB(o1, u, c[3]);
+            ex[(wave * 16 + i * 8 + q) * 64 + lane] = f32x4{o0.x, o0.y, o1.x, o1.y};
         }
     __syncthreads();
 
-    if (vec2) {
-        // Even rows: sixteen aligned float2 outputs per lane (mask and style term were requested
-        // ahead of the exchange, see above; the content term, one layer per tile evaluation,
-        // is read here, when the accumulators no longer occupy registers).
-        if (EPI == kEpiDgradInject && a.inj.content) {
+    if (weven) {
+        const float *const content = a.inj.content;
+        const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
+                  cw_ox = a.inj.win.ox - a.inj.win.sx;
+        auto content_at = [&](int c, int y, int x) __attribute__((always_inline)) {   // common.h: content_index
+            int ry_ = (cw_oy + y) % cw_ch, rx_ = (cw_ox + x) % cw_cw;
+            if (ry_ < 0) ry_ += cw_ch;
+            if (rx_ < 0) rx_ += cw_cw;
+            return content[((size_t)c * cw_ch + ry_) * cw_cw + rx_];
+        };
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                ft[n] = *reinterpret_cast<const float2 *>(a.inj.feat + idx[n]);
-                const int cy = ok[n] ? yy + (n & 1) : 0, cx = ok[n] ? xx0 : 0;
-                const int cm = ok[n] ? mm[n] : 0;
-                ct[n].x = a.inj.content[content_index(a.inj.win, cm, cy, cx)];
-                ct[n].y = a.inj.content[content_index(a.inj.win, cm, cy, cx + 1 < a.W ? cx + 1 : cx)];
-            }
-        }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int n = 0; n < 16; n += 2) {
-            const int i = n >> 3, rr = (n >> 1) & 3, r = 4 * xi + rr;
-            float2 p[4];
+            for (int qq = 0; qq < 2; ++qq) {
+                f32x4 p[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) p[x] = ex[((trow * 4 + x) * 32 + i * 16 + r) * 64 + lane];
-            float2 o[2] = {make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
-                           make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y)};
+                for (int x = 0; x < 4; ++x)
+                    p[x] = ex[((trow * 4 + x) * 16 + i * 8 + 2 * xi + qq) * 64 + lane];
+                // rows[y][e] = (channel a, channel b) of output row y, column e
+                f32x2 rows[2][2];
 #pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                const int q = n + y;
-                float2 v = o[y];
-                if (EPI == kEpiPartial) {
-                    if (ok[q]) *reinterpret_cast<float2 *>(a.y + (long)kslice * a.M * HW + idx[q]) = v;
-                    continue;
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2 p0 = e ? p[0].zw : p[0].xy, p1 = e ? p[1].zw : p[1].xy;
+                    const f32x2 p2 = e ? p[2].zw : p[2].xy, p3 = e ? p[3].zw : p[3].xy;
+                    f32x2 t, u;
+                    STX_PK_ADD(t, p0, p1);
+                    STX_PK_ADD(rows[0][e], t, p2);
+                    STX_PK_SUB(u, p1, p2);
+                    STX_PK_SUB(rows[1][e], u, p3);
                 }
-                if (EPI == kEpiForward) {
-                    if (a.bias) v.x += bs[q], v.y += bs[q];
-                    if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
-                    o[y] = v;
-                } else {
-                    if (a.mask) {
-                        v.x = mk[q].x > 0.f ? v.x : 0.f;
-                        v.y = mk[q].y > 0.f ? v.y : 0.f;
-                    }
-                    if (EPI == kEpiDgradInject) {
-                        if (a.inj.content) {
-                            v.x += c_scale * (ft[q].x - ct[q].x);
-                            v.y += c_scale * (ft[q].y - ct[q].y);
+                if (EPI == kEpiForward && a.bias) {
+                    const f32x2 bb = {bs[i * 4 + 2 * qq], bs[i * 4 + 2 * qq + 1]};
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) STX_PK_ADD(rows[y][e], rows[y][e], bb);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {           // the two channels of the register pair
+                    const int rr = 2 * qq + h, c = chan(i, rr);
+                    const unsigned so = (unsigned)c * HW4;
+                    f32x2 o[2];
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        const int n = (i * 4 + rr) * 2 + y;
+                        f32x2 v = {h ? rows[y][0].y : rows[y][0].x, h ? rows[y][1].y : rows[y][1].x};
+                        if (EPI == kEpiForward) {
+                            if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+                        } else if (EPI != kEpiPartial) {
+                            if (a.mask) {
+                                v.x = mk[n].x > 0.f ? v.x : 0.f;
+                                v.y = mk[n].y > 0.f ? v.y : 0.f;
+                            }
+                            if (EPI == kEpiDgradInject) {
+                                if (content) {
+                                    // (one layer per tile evaluation takes this: the content map
+                                    // is read where it is used, not ahead of time)
+                                    const f32x2 ft = ld2(rft, y, so);
+                                    const int mm = c + 4 * half;
+                                    const bool ok = yy + y < a.H && xx0 < a.W && mm < a.M;
+                                    const int cy = ok ? yy + y : 0, cx = ok ? xx0 : 0, cm = ok ? mm : 0;
+                                    v.x += c_scale * (ft.x - content_at(cm, cy, cx));
+                                    v.y += c_scale * (ft.y - content_at(cm, cy, cx + 1 < a.W ? cx + 1 : cx));
+                                }
+                                if (a.inj.sgrad) {
+                                    v.x += s_scale * sg[n].x;
+                                    v.y += s_scale * sg[n].y;
+                                }
+                            }
                         }
-                        if (a.inj.sgrad) {
-                            v.x += s_scale * sg[q].x;
-                            v.y += s_scale * sg[q].y;
+                        o[y] = v;
+                        st2(y, so, v);
+                    }
+                    // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
+                    // that follows (ceil mode: the second row may be missing): pool.hip's
+                    // arithmetic (the divisor is 4 or 2: the product with its reciprocal is the
+                    // same float)
+                    if (EPI == kEpiForward && a.pool_out) {
+                        const bool hy = yy + 1 < a.H;
+                        float pr;
+                        if (a.pool_mode == STX_POOL_MAX) {
+                            pr = fmaxf(o[0].x, o[0].y);
+                            pr = hy ? fmaxf(fmaxf(pr, o[1].x), o[1].y) : pr;
+                        } else {
+                            pr = (o[0].x + o[0].y + (hy ? o[1].x : 0.f) + (hy ? o[1].y : 0.f)) *
+                                 (hy ? 0.25f : 0.5f);
                         }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, vpool,
+                                                              (unsigned)c * (unsigned)(ph * pw * 4), 0);
                     }
                 }
-                if (ok[q]) *reinterpret_cast<float2 *>(a.y + idx[q]) = v;
             }
-            // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer that
-            // follows (ceil mode: the second row may be missing): pool.hip's arithmetic
-            if (EPI == kEpiForward && a.pool_out && ok[n]) {
-                const bool hy = ok[n + 1];
-                float r;
-                if (a.pool_mode == STX_POOL_MAX) {
-                    r = fmaxf(o[0].x, o[0].y);
-                    if (hy) r = fmaxf(fmaxf(r, o[1].x), o[1].y);
-                } else {
-                    r = (o[0].x + o[0].y + (hy ? o[1].x : 0.f) + (hy ? o[1].y : 0.f)) / (hy ? 4.f : 2.f);
-                }
-                const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
-                a.pool_out[((long)mm[n] * ph + (yy >> 1)) * pw + (xx0 >> 1)] = r;
-            }
-        }
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -595,7 +671,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             const int r = 4 * xi + rr;
             float2 p[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) p[x] = ex[((trow * 4 + x) * 32 + i * 16 + r) * 64 + lane];
+            for (int x = 0; x < 4; ++x) {
+                const f32x4 e4 = ex[((trow * 4 + x) * 16 + i * 8 + (r >> 1)) * 64 + lane];
+                p[x] = (r & 1) ? make_float2(e4.y, e4.w) : make_float2(e4.x, e4.z);
+            }
             const int m = m0 + i * 32 + rr + 8 * xi + 4 * half;
             finish_pair<EPI>(a, false, HW, kslice, m, yy, xx0,
                              make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
@@ -605,6 +684,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                              s_scale, c_scale);
         }
     }
+#undef STX_PK_ADD
+#undef STX_PK_SUB
 #ifdef STX_WINO2_TIMING
     if (blockIdx.x == 0 && lane == 0) {
         g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = t_barrier;

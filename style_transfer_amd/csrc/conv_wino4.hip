@@ -312,6 +312,10 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(WinoArgs a) {
     using no = std::integral_constant<bool, false>;
 
     load_stage(c_begin);
+    // clear the accumulators while the first loads are in flight (the compiler would sink the 256
+    // moves to just before the first MFMA, behind the barrier)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) asm volatile("" : "+a"(acc[c]));
     store_stage(0);
     if (c_begin + 1 < c_end) load_stage(c_begin + 1);
     lds_barrier();
