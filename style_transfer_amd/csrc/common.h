@@ -164,6 +164,7 @@ int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 // 211 (16 x 16), 212 (8 x 32).  Shares the packed bank, the pooling rule and the K-split model.
 ConvConfig wino4_config(int geometry = 0);
 int wino4_pick_geometry(int K, int M, int H, int W);
+double wino4_geometry_cost(int geometry, int K, int M, int H, int W);   // model microseconds
 int wino4_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.

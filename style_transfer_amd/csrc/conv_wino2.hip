@@ -92,71 +92,6 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-// The shared tail of every output pair: (m, yy, xx0) and (m, yy, xx0 + 1).
-template <int EPI>
-__device__ __forceinline__ void finish_pair(const WinoArgs &a, bool vec2, int HW, int kslice, int m,
-                                            int yy, int xx0, float2 v, float s_scale,
-                                            float c_scale) {
-    if (yy >= a.H || m >= a.M) return;
-    if (vec2) {
-        if (xx0 >= a.W) return;
-        const long idx = (long)m * HW + yy * a.W + xx0;
-        if (EPI == kEpiPartial) {
-            *reinterpret_cast<float2 *>(a.y + (long)kslice * a.M * HW + idx) = v;
-            return;
-        }
-        if (EPI == kEpiForward) {
-            if (a.bias) v.x += a.bias[m], v.y += a.bias[m];
-            if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
-        } else {
-            if (a.mask) {
-                const float2 k = *reinterpret_cast<const float2 *>(a.mask + idx);
-                v.x = k.x > 0.f ? v.x : 0.f;
-                v.y = k.y > 0.f ? v.y : 0.f;
-            }
-            if (EPI == kEpiDgradInject) {
-                if (a.inj.content) {
-                    const float2 f = *reinterpret_cast<const float2 *>(a.inj.feat + idx);
-                    v.x += c_scale * (f.x - a.inj.content[content_index(a.inj.win, m, yy, xx0)]);
-                    v.y += c_scale * (f.y - a.inj.content[content_index(a.inj.win, m, yy, xx0 + 1)]);
-                }
-                if (a.inj.sgrad) {
-                    const float2 g = *reinterpret_cast<const float2 *>(a.inj.sgrad + idx);
-                    v.x += s_scale * g.x;
-                    v.y += s_scale * g.y;
-                }
-            }
-        }
-        *reinterpret_cast<float2 *>(a.y + idx) = v;
-        return;
-    }
-    const float out[2] = {v.x, v.y};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int xx = xx0 + e;
-        if (xx >= a.W) continue;
-        const long idx = (long)m * HW + yy * a.W + xx;
-        float o = out[e];
-        if (EPI == kEpiPartial) {
-            a.y[(long)kslice * a.M * HW + idx] = o;
-            continue;
-        }
-        if (EPI == kEpiForward) {
-            if (a.bias) o += a.bias[m];
-            if (a.relu) o = fmaxf(o, 0.f);
-        } else {
-            if (a.mask) o = a.mask[idx] > 0.f ? o : 0.f;
-            if (EPI == kEpiDgradInject) {
-                if (a.inj.content)
-                    o += c_scale *
-                         (a.inj.feat[idx] - a.inj.content[content_index(a.inj.win, m, yy, xx)]);
-                if (a.inj.sgrad) o += s_scale * a.inj.sgrad[idx];
-            }
-        }
-        a.y[idx] = o;
-    }
-}
-
 }  // namespace
 
 template <int EPI, int TXW>
@@ -488,12 +423,15 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int yy = y0 + 2 * (trow * TYW + l31 / TXW), xx0 = x0 + 2 * (l31 % TXW);
     const unsigned plane_bytes = (unsigned)a.M * (unsigned)HW * 4u;
     const unsigned HW4 = (unsigned)HW * 4u;
-    unsigned vo[2];                           // first column of the lane's two output rows
+    unsigned vo[2][2];                        // [row][column] of the lane's 2 x 2 outputs
     {
         const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
 #pragma unroll
         for (int y = 0; y < 2; ++y)
-            vo[y] = (yy + y < a.H && xx0 < a.W) ? lane_base + (unsigned)(y * a.W) * 4u : kOob;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                vo[y][e] = (yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u
+                                                           : kOob;
     }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
@@ -518,11 +456,24 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         const int c = m0 + i * 32 + rr + 8 * xi;
         return sgpr(c < M_ ? c : M_);
     };
-    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so) __attribute__((always_inline)) {
-        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y], so, 0));
+    // even plane widths: a lane's two columns are one aligned 8-byte access; odd widths: two
+    // dword accesses (a pair may straddle the end of a row)
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, auto even_c) __attribute__((always_inline)) {
+        if (decltype(even_c)::value)
+            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y][0], so, 0));
+        f32x2 v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][0], so, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
+        return v;
     };
-    auto st2 = [&](int y, unsigned so, f32x2 v) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), ry, vo[y], so, 0);
+    auto st2 = [&](int y, unsigned so, f32x2 v, auto even_c) __attribute__((always_inline)) {
+        if (decltype(even_c)::value) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), ry, vo[y][0], so, 0);
+        } else {
+            const float v0 = v.x, v1 = v.y;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ry, vo[y][1], so, 0);
+        }
     };
     // The ReLU mask and the style term are requested before the exchange of the transform rows
     // through LDS, for all sixteen outputs of the lane; the values land during the exchange.
@@ -530,9 +481,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // measured twice as slow.)
     f32x2 mk[16], sg[16];
     float bs[8];
-    if (!weven) {
-        // odd widths: the scalar path below does its own reads
-    } else if (EPI == kEpiForward) {
+    if (EPI == kEpiForward) {
         if (a.bias) {
 #pragma unroll
             for (int n = 0; n < 8; ++n)
@@ -541,14 +490,18 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                                                       (unsigned)chan(n >> 2, n & 3) * 4u, 0));
         }
     } else if (EPI != kEpiPartial) {
+        auto prefetch = [&](auto even_c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            const unsigned so = (unsigned)chan(n >> 3, (n >> 1) & 3) * HW4;
-            if (a.mask) mk[n] = ld2(rmask, n & 1, so);
-            if (EPI == kEpiDgradInject) {
-                if (a.inj.sgrad) sg[n] = ld2(rsg, n & 1, so);
+            for (int n = 0; n < 16; ++n) {
+                const unsigned so = (unsigned)chan(n >> 3, (n >> 1) & 3) * HW4;
+                if (a.mask) mk[n] = ld2(rmask, n & 1, so, even_c);
+                if (EPI == kEpiDgradInject) {
+                    if (a.inj.sgrad) sg[n] = ld2(rsg, n & 1, so, even_c);
+                }
             }
-        }
+        };
+        if (weven) prefetch(yes{});
+        else prefetch(no{});
     }
 
     // exchange: [wave][i][register pair q][lane] x (col 0 of r, col 0 of r + 1, col 1 of r, col 1
@@ -571,7 +524,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         }
     __syncthreads();
 
-    if (weven) {
+    {
         const float *const content = a.inj.content;
         const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
                   cw_ox = a.inj.win.ox - a.inj.win.sx;
@@ -581,6 +534,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             if (rx_ < 0) rx_ += cw_cw;
             return content[((size_t)c * cw_ch + ry_) * cw_cw + rx_];
         };
+        auto tail = [&](auto even_c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -628,7 +582,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                                 if (content) {
                                     // (one layer per tile evaluation takes this: the content map
                                     // is read where it is used, not ahead of time)
-                                    const f32x2 ft = ld2(rft, y, so);
+                                    const f32x2 ft = ld2(rft, y, so, even_c);
                                     const int mm = c + 4 * half;
                                     const bool ok = yy + y < a.H && xx0 < a.W && mm < a.M;
                                     const int cy = ok ? yy + y : 0, cx = ok ? xx0 : 0, cm = ok ? mm : 0;
@@ -642,7 +596,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             }
                         }
                         o[y] = v;
-                        st2(y, so, v);
+                        st2(y, so, v, even_c);
                     }
                     // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
                     // that follows (ceil mode: the second row may be missing): pool.hip's
@@ -663,26 +617,9 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                     }
                 }
             }
-    } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * xi + rr;
-            float2 p[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const f32x4 e4 = ex[((trow * 4 + x) * 16 + i * 8 + (r >> 1)) * 64 + lane];
-                p[x] = (r & 1) ? make_float2(e4.y, e4.w) : make_float2(e4.x, e4.z);
-            }
-            const int m = m0 + i * 32 + rr + 8 * xi + 4 * half;
-            finish_pair<EPI>(a, false, HW, kslice, m, yy, xx0,
-                             make_float2(p[0].x + p[1].x + p[2].x, p[0].y + p[1].y + p[2].y),
-                             s_scale, c_scale);
-            finish_pair<EPI>(a, false, HW, kslice, m, yy + 1, xx0,
-                             make_float2(p[1].x - p[2].x - p[3].x, p[1].y - p[2].y - p[3].y),
-                             s_scale, c_scale);
-        }
+        };
+        if (weven) tail(yes{});
+        else tail(no{});
     }
 #undef STX_PK_ADD
 #undef STX_PK_SUB

@@ -580,6 +580,10 @@ static double wino4_cost(const ConvConfig &cfg, int K, int M, int H, int W) {
     return best_cost;
 }
 
+double wino4_geometry_cost(int geometry, int K, int M, int H, int W) {
+    return wino4_cost(wino4_config(geometry), K, M, H, W);
+}
+
 int wino4_pick_geometry(int K, int M, int H, int W) {
     int best = 0;
     double best_cost = 0;

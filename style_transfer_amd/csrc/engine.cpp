@@ -317,7 +317,8 @@ static std::map<std::vector<int>, int> g_tuned;
 // choice depends on the shape only, never on timing: the rounding differs between the kernels,
 // and a given shape must always take the same path.  STX_CONV_ALGO=direct|wino1|wino2 (read at
 // every call) overrides it for tests and measurements.
-static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out) {
+static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out,
+                        bool inject = false) {
     if (ksize != 3 || K < 8 || M <= 4) return false;
     const char *algo = getenv("STX_CONV_ALGO");
     if (algo && *algo) {
@@ -338,18 +339,22 @@ static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, Co
         return true;
     }
     // Two kernels with identical arithmetic (bit-identical results).  The eight-wave one is a
-    // percent or two faster on the even, power-of-two-ish planes of the benchmark tile and has
-    // the registers to request everything a loss-injecting epilogue reads at once; the four-wave
-    // one has a third patch geometry chosen by a cost model and a branch-free path for odd
-    // widths (measured on the planes of 724- and 362-pixel tiles: 0.211 -> 0.200 ms at 181 x 181,
-    // 0.077 -> 0.062 at 46 x 46).  Shape only, never timing.
+    // percent or two faster where both offer the same patch geometry and has the registers to
+    // request everything a loss-injecting epilogue reads at once (the four-wave one spills
+    // there: 0.63 vs 0.44 ms on the 965 x 965 plane of conv1_2's backward pass); the four-wave
+    // one has a third patch geometry (8 x 32 pixels), which decides on the small odd planes of
+    // a pyramid (91 x 91, 46 x 46: fewer, fuller rounds of workgroups).  Model cost of the best
+    // geometry of each, with those handicaps.  Shape only, never timing.
     const int g4 = wino4_pick_geometry(K, M, H, W), g2 = wino2_pick_geometry(H, W);
-    *out = ((W & 1) || g4 != g2) ? wino4_config(g4) : wino2_config(g2);
+    const double t4 = wino4_geometry_cost(g4, K, M, H, W) * (inject ? 1.12 : 1.02);
+    const double t2 = wino4_geometry_cost(g2, K, M, H, W);
+    *out = t4 < t2 ? wino4_config(g4) : wino2_config(g2);
     return true;
 }
 
-int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out) {
-    if (wino_choice(e, p.ksize, p.K, p.M, p.H, p.W, out)) return STX_OK;
+int choose_conv_config(stx_engine *e, int li, int dir, ConvProblem p, ConvConfig *out,
+                       bool inject = false) {
+    if (wino_choice(e, p.ksize, p.K, p.M, p.H, p.W, out, inject)) return STX_OK;
     const ConvConfig fallback = conv_pick_config(p.ksize, p.K, p.M, p.H, p.W);
     *out = fallback;
     if (!e->autotune || p.ksize != 3 || p.K <= 4 || p.M <= 32) return STX_OK;
@@ -490,7 +495,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
         return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
     }
     ConvConfig cfg;
-    STX_TRY(choose_conv_config(e, li, 1, p, &cfg));   // tuned without the injection terms
+    STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
