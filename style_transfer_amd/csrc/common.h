@@ -44,6 +44,25 @@ void set_error(const char *fmt, ...);
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int pooled_len(int n) { return n >= 2 ? (n - 2 + 1) / 2 + 1 : 1; }  // ceil((n-2)/2)+1
+#ifdef __HIPCC__
+// Window codes of the 2x2/2 pooling (pool.hip): what the backward pass needs to know about a window.
+// MAX: index of the FIRST maximum in row-major order (strict '>' scan, as Caffe's) | 4 if it is > 0.
+__device__ __forceinline__ unsigned pool_max_code(float v00, float v01, float v10, float v11, bool hx,
+                                                  bool hy) {
+    unsigned arg = 0;
+    float best = v00;
+    if (hx && v01 > best) best = v01, arg = 1;
+    if (hy && v10 > best) best = v10, arg = 2;
+    if (hx && hy && v11 > best) best = v11, arg = 3;
+    return arg | (best > 0.f ? 4u : 0u);
+}
+// AVE: bit k set if element k of the window is > 0 (the ReLU mask of the blob below).
+__device__ __forceinline__ unsigned pool_ave_code(float v00, float v01, float v10, float v11, bool hx,
+                                                  bool hy) {
+    return (v00 > 0.f ? 1u : 0u) | (hx && v01 > 0.f ? 2u : 0u) | (hy && v10 > 0.f ? 4u : 0u) |
+           (hx && hy && v11 > 0.f ? 8u : 0u);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Kernel launchers (each enqueues on `stream` and returns STX_OK / STX_ERR_*).
@@ -89,6 +108,7 @@ struct ConvProblem {
     int relu;              // kEpiForward
     int epilogue;
     ConvInject inject;     // kEpiDgrad, optional
+    unsigned char *pool_codes = nullptr;   // with pool_out: one window code per pooled element (pool.hip)
     float *pool_out = nullptr;       // kEpiForward: also write the 2x2/2 ceil-mode pooling of y here
     int pool_mode = 0;               // (kernels that cannot do it leave it to the caller: see
                                      // wino2_fuses_pool)
@@ -139,6 +159,7 @@ struct WinoArgs {
     ConvInject inj;
     float *pool_out;       // forward only: 2x2/2 pooling of the output, or null
     int pool_mode;
+    unsigned char *pool_codes;   // with pool_out: window codes for the backward pass, or null
 };
 
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
@@ -174,7 +195,10 @@ int conv_small_pack(hipStream_t s, const float *w_caffe, int Mo, int Ko, int tra
 int conv_small_launch(hipStream_t s, const float *x, const float *packed, float *y,
                       const float *mask, int K, int M, int H, int W);
 
-int pool_forward_launch(hipStream_t s, const float *x, int C, int H, int W, int mode, float *y);
+int pool_forward_launch(hipStream_t s, const float *x, int C, int H, int W, int mode, float *y,
+                        unsigned char *codes = nullptr);
+int pool_backward_codes_launch(hipStream_t s, const float *dy, const unsigned char *codes, int C,
+                               int H, int W, int mode, bool relu_mask, float *dx);
 // dx = route(dy) [* (x > 0) when masked]; x is the pool input data (post-ReLU).
 int pool_backward_launch(hipStream_t s, const float *dy, const float *x, int C, int H, int W,
                          int mode, bool relu_mask, float *dx);

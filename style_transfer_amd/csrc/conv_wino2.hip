@@ -446,6 +446,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
         a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_codes, 0, a.pool_codes ? a.M * ph * pw : 0, 0x00020000);
     const unsigned vpool = (yy < a.H && xx0 < a.W)
                                ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
                                : kOob;
@@ -614,6 +616,14 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                         }
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, vpool,
                                                               (unsigned)c * (unsigned)(ph * pw * 4), 0);
+                        if (a.pool_codes) {       // what the backward pass needs of this window
+                            const unsigned code =
+                                a.pool_mode == STX_POOL_MAX
+                                    ? pool_max_code(o[0].x, o[0].y, o[1].x, o[1].y, true, hy)
+                                    : pool_ave_code(o[0].x, o[0].y, o[1].x, o[1].y, true, hy);
+                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rcodes, vpool >> 2,
+                                                                 (unsigned)c * (unsigned)(ph * pw), 0);
+                        }
                     }
                 }
             }
@@ -778,6 +788,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.relu = p.relu;
     a.inj = p.inject;
     a.pool_out = nullptr;
+    a.pool_codes = nullptr;
     a.pool_mode = p.pool_mode;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);
@@ -797,6 +808,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         n_wg *= ksplit;
     } else if (p.epilogue == kEpiForward && wino2_fuses_pool(p)) {
         a.pool_out = p.pool_out;
+        a.pool_codes = p.pool_codes;
     }
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
 #define STX_W2_CASE(E)                                                                            \

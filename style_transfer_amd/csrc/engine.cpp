@@ -76,6 +76,8 @@ struct Blob {
     int scale = 1;       // 224 // height at a 224 input (CaffeModel.layer_info, style_transfer.py:415-419)
     int h = 0, w = 0;    // current tile
     DevBuf data, diff;
+    DevBuf codes;             // pooled blobs: one window code per element (pool.hip), written by the
+    bool codes_valid = false; // forward pass that produced `data` if its kernel can
     size_t count() const { return (size_t)channels * h * w; }
 };
 
@@ -142,6 +144,7 @@ struct stx_engine {
 
     bool winograd = true;   // 1-D Winograd F(2,3) for the 3x3 layers (STX_WINOGRAD=0: direct only)
     bool autotune = true;   // tile-config autotuning (process-wide cache, see choose_conv_config)
+    bool pool_codes = true; // forward pooling leaves window codes for the backward pass (STX_POOL_CODES=0: off)
 
     // optional per-kernel-group timing (stx_profile_enable): event pairs around launch groups
     bool profiling = false;
@@ -453,10 +456,20 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     STX_TRY(attach_splitk(e, cfg, p));
     if (pooled) *pooled = false;
     if (pool) {
-        p.pool_out = e->blobs[pool->top_blob].data.f();
+        Blob &pt = e->blobs[pool->top_blob];
+        p.pool_out = pt.data.f();
         p.pool_mode = pool->pool_mode;
-        if (conv_fuses_pool(cfg, p)) *pooled = true;
-        else p.pool_out = nullptr;
+        pt.codes_valid = false;
+        if (conv_fuses_pool(cfg, p)) {
+            *pooled = true;
+            if (cfg.id < 210 && e->pool_codes) {       // (the four-wave kernel does not write them)
+                STX_TRY(pt.codes.ensure(pt.count()));
+                p.pool_codes = static_cast<unsigned char *>(pt.codes.ptr);
+                pt.codes_valid = true;
+            }
+        } else {
+            p.pool_out = nullptr;
+        }
     }
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return launch_conv(e, cfg, p);
@@ -544,8 +557,15 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
             continue;
         } else {
             ProfScope scope(e, "fwd " + L.name, 0.0);
+            unsigned char *codes = nullptr;
+            t.codes_valid = false;
+            if (e->pool_codes) {
+                STX_TRY(t.codes.ensure(t.count()));
+                codes = static_cast<unsigned char *>(t.codes.ptr);
+                t.codes_valid = true;
+            }
             STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
-                                        t.data.f()));
+                                        t.data.f(), codes));
             if (t.relu || L.top_blob == relu_blob)
                 STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
             if (after_blob) STX_TRY((*after_blob)(L.top_blob));
@@ -746,6 +766,7 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     STX_HIP(hipEventCreate(&e->ev_tune0));
     STX_HIP(hipEventCreate(&e->ev_tune1));
     if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
+    if (const char *env = getenv("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
     if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
     e->scalars_cap = kScalarFloats;
     STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
@@ -771,6 +792,7 @@ void stx_engine_destroy(stx_engine *e) {
     for (Blob &b : e->blobs) {
         b.data.release();
         b.diff.release();
+        b.codes.release();
     }
     for (auto &kv : e->conv) {
         kv.second.w.release();
@@ -1262,8 +1284,13 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             STX_TRY(run_conv_backward(e, li, fused ? &inj : nullptr, &fused));
         } else {
             ProfScope scope(e, "bwd " + L.name, 0.0);
-            STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels, bot.h,
-                                         bot.w, L.pool_mode, bot.relu, bot.diff.f()));
+            if (top.codes_valid)
+                STX_TRY(pool_backward_codes_launch(
+                    e->stream, top.diff.f(), static_cast<const unsigned char *>(top.codes.ptr),
+                    bot.channels, bot.h, bot.w, L.pool_mode, bot.relu, bot.diff.f()));
+            else
+                STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels,
+                                             bot.h, bot.w, L.pool_mode, bot.relu, bot.diff.f()));
         }
         cur = L.bottom_blob;
         if (k >= 0 && !fused) {
