@@ -241,9 +241,14 @@ __global__ __launch_bounds__(256, 2) void gram_partial_wide_kernel(const float *
         // to the next slice or the next channel row and must not count
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const bool ok = p0 + ((tid + 256 * n) & 15) * 4 < p_end;
+            // pixels left in the slice from this vector's first one (a plane size that is not a
+            // multiple of 4 ends inside a vector: the rest of it is the next channel's row)
+            const int rem = p_end - (p0 + ((tid + 256 * n) & 15) * 4);
             u32x4g va = ra[n], vb = rb[n];
-            if (!ok) va = u32x4g{0, 0, 0, 0}, vb = u32x4g{0, 0, 0, 0};
+            if (rem < 4) {
+                va.x = rem > 0 ? va.x : 0u, va.y = rem > 1 ? va.y : 0u, va.z = rem > 2 ? va.z : 0u, va.w = 0u;
+                vb.x = rem > 0 ? vb.x : 0u, vb.y = rem > 1 ? vb.y : 0u, vb.z = rem > 2 ? vb.z : 0u, vb.w = 0u;
+            }
             *reinterpret_cast<u32x4g *>(At + ldst[n]) = va;
             if (!diag) *reinterpret_cast<u32x4g *>(Bt + ldst[n]) = vb;
         }
@@ -316,7 +321,8 @@ int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan,
     slice = ceil_div(slice, kGP) * kGP;
     const bool aligned = (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
     const double bytes = 4.0 * plan.C * (double)plan.HW;
-    if (plan.HW % 4 == 0 && aligned && bytes < 2147483648.0 && !getenv("STX_GRAM_NARROW")) {
+    // (buffer loads need dword alignment only: odd plane sizes take the wide kernel too)
+    if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && !getenv("STX_GRAM_NARROW")) {
         gram_partial_wide_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
             feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, partials);
         STX_CHECK_LAUNCH();
