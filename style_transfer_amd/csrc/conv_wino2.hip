@@ -540,12 +540,25 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         const float *const content = a.inj.content;
         const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
                   cw_ox = a.inj.win.ox - a.inj.win.sx;
-        auto content_at = [&](int c, int y, int x) __attribute__((always_inline)) {   // common.h: content_index
-            int ry_ = (cw_oy + y) % cw_ch, rx_ = (cw_ox + x) % cw_cw;
-            if (ry_ < 0) ry_ += cw_ch;
-            if (rx_ < 0) rx_ += cw_cw;
-            return content[((size_t)c * cw_ch + ry_) * cw_cw + rx_];
-        };
+        // common.h: content_index -- the wrapped row / column of the lane's 2 x 2 outputs in the
+        // full-image content map, once per lane (two integer divisions per OUTPUT were ~1300
+        // vector instructions of this epilogue on the content layer)
+        int crow[2] = {0, 0}, ccol[2] = {0, 0};
+        if (EPI == kEpiDgradInject && content) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const bool ok = yy + y < a.H && xx0 < a.W;
+                int r = (cw_oy + (ok ? yy + y : 0)) % cw_ch;
+                crow[y] = (r < 0 ? r + cw_ch : r) * cw_cw;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool ok = yy < a.H && xx0 < a.W;
+                const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
+                int r = (cw_ox + x) % cw_cw;
+                ccol[e] = r < 0 ? r + cw_cw : r;
+            }
+        }
         auto tail = [&](auto even_c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -596,10 +609,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                                     // is read where it is used, not ahead of time)
                                     const f32x2 ft = ld2(rft, y, so, even_c);
                                     const int mm = c + 4 * half;
-                                    const bool ok = yy + y < a.H && xx0 < a.W && mm < a.M;
-                                    const int cy = ok ? yy + y : 0, cx = ok ? xx0 : 0, cm = ok ? mm : 0;
-                                    v.x += c_scale * (ft.x - content_at(cm, cy, cx));
-                                    v.y += c_scale * (ft.y - content_at(cm, cy, cx + 1 < a.W ? cx + 1 : cx));
+                                    const int cm = mm < a.M ? mm : 0;     // (lanes past M store nothing)
+                                    const float *cp = content + (size_t)cm * cw_ch * cw_cw + crow[y];
+                                    v.x += c_scale * (ft.x - cp[ccol[0]]);
+                                    v.y += c_scale * (ft.y - cp[ccol[1]]);
                                 }
                                 if (a.inj.sgrad) {
                                     v.x += s_scale * sg[n].x;
