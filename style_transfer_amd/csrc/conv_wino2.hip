@@ -409,8 +409,17 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         cur ^= 1;
         ++chunk;
     }
-    run_chunk(cur, chunk, no{}, no{});
-    lds_barrier();
+    // The backward epilogues read up to two arrays of the output's size (ReLU mask, style term):
+    // 128 KB per workgroup, and the 256 workgroups of a round ask for theirs at the same moment.
+    // Those reads are requested BEFORE the last chunk of matrix work and land during it (the
+    // staging registers are free by then; with the pointer-arithmetic epilogue of round 1 this
+    // spilled).  The forward epilogue only reads a bias vector and is set up after the chunk
+    // (measured: 3-5 us slower per layer the other way round).
+    constexpr bool kEarly = EPI == kEpiDgrad || EPI == kEpiDgradInject;
+    if (!kEarly) {
+        run_chunk(cur, chunk, no{}, no{});
+        lds_barrier();
+    }
 
     float s_scale = 0.f, c_scale = 0.f;
     if (EPI == kEpiDgradInject) {
@@ -487,10 +496,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ry, vo[y][1], so, 0);
         }
     };
-    // The ReLU mask and the style term are requested before the exchange of the transform rows
-    // through LDS, for all sixteen outputs of the lane; the values land during the exchange.
-    // (Requested ahead of the last chunk of matrix work they make the compiler spill around it:
-    // measured twice as slow.)
+    // The ReLU mask and the style term, for all sixteen outputs of the lane (see kEarly above).
     f32x2 mk[16], sg[16];
     float bs[8];
     if (EPI == kEpiForward) {
@@ -514,6 +520,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         };
         if (weven) prefetch(yes{});
         else prefetch(no{});
+    }
+
+    if (kEarly) {
+        run_chunk(cur, chunk, no{}, no{});
+        lds_barrier();
     }
 
     // exchange: [wave][i][register pair q][lane] x (col 0 of r, col 0 of r + 1, col 1 of r, col 1
