@@ -23,24 +23,14 @@
 // Staging.  Per chunk of 8 input channels: the transformed filter bank comes as a ready LDS
 // image (32 KB, four b128 loads per thread); the input patch is transformed on its way in, one
 // (channel, tile) per thread: sixteen loads -> Bt d B in registers -> four b128 LDS writes.  The
-// chunk is double buffered in LDS (2 x 64 KB), one barrier per chunk; the workgroup has the CU to
-// itself.
+// chunk is double buffered in LDS (2 x 64 KB), one barrier per chunk (inside it, before its last
+// k-step); the workgroup has the CU to itself.  DESIGN.md section 3.3 has the cycle budget.
 
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
-
-#ifdef STX_ABLATE
-#define STX_ABLATE_V STX_ABLATE
-#else
-#define STX_ABLATE_V 0
-#endif
-
-#ifndef STX_W2_BURST
-#define STX_W2_BURST 1
-#endif
 
 #ifndef STX_W2_SKIP
 #define STX_W2_SKIP 0   // timing experiments (tools/ubench/wino2_bench.hip): 1 no filter loads, 2 no patch
@@ -81,15 +71,8 @@ __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstla
 
 // LDS traffic of this wave complete, then the workgroup barrier.  Unlike __syncthreads() this does
 // not wait for the global loads in flight for the chunk after next (vmcnt is left alone).
-#ifndef STX_W2_LDSBAR
-#define STX_W2_LDSBAR 1
-#endif
 __device__ __forceinline__ void lds_barrier() {
-#if STX_W2_LDSBAR
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 
 }  // namespace
@@ -118,13 +101,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // instead of 16.8 + 3.2 (512 -> 512 channels; tools/pmc_layers.py)
     int ptile = sgpr(Lt / m_tiles);
     int mtile = Lt - ptile * m_tiles;
-#ifndef STX_W2_NOBLOCK
     if (m_tiles == 8 && ((a.tiles_x * a.tiles_y) & 7) == 0) {
         const int g = Lt >> 5, r = Lt & 31;
         mtile = (g & 1) * 4 + (r & 3);
         ptile = (g >> 1) * 8 + (r >> 2);
     }
-#endif
     const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
     const int c_end = sgpr(EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks);
     const int y0 = sgpr((ptile / a.tiles_x) * PR);
@@ -178,13 +159,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     f32x4 vq[4];       // Bt d B, one transform row each
 
     // The hand-over of a chunk from the staging registers to LDS, cut into single-instruction
-    // pieces.  While a wave's SIMD partner has an MFMA in flight (64 cycles) the wave can issue a
-    // handful of other instructions for free, but a wave that presents nothing but MFMAs leaves
-    // its partner one issue slot per MFMA: a contiguous block of ~40 staging instructions in one
-    // wave then takes longer than the partner's whole chunk of matrix work (measured,
-    // tools/ubench/coissue.hip).  So the pieces are dealt out one per MFMA.  Bt d B is sixteen
-    // packed adds (v_pk_add_f32 with operand-select / negate modifiers, which the compiler does
-    // not form by itself); the results stay in their own registers until they are written.
+    // pieces.  Memory and LDS instructions ride in the 64-cycle shadow of an MFMA for free (one
+    // per MFMA: tools/ubench/solo_issue.hip, coissue.hip), so those pieces are dealt out one per
+    // MFMA; vector instructions are never hidden, the first one after an MFMA costs ~13 cycles
+    // and every further one of the same burst ~4, so Bt d B is ONE burst: sixteen packed adds
+    // (v_pk_add_f32 with operand-select / negate modifiers, which the compiler does not form by
+    // itself); the results stay in their own registers until they are written.
 #define STX_PK(dst, a_, b_, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(dst) : "v"(a_), "v"(b_))
     auto u_load = [&](int n, unsigned ws) {
         wreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + n * NT) * 16u, ws, 0);
@@ -283,8 +263,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 
     // One chunk of matrix work out of LDS buffer `cur`, with (STORE) the hand-over of the next
     // chunk into the other buffer and (LOAD) the loads of the chunk after that dealt out between
-    // the MFMAs: pieces 0-3 filter-bank writes, 4-7 filter-bank loads, 8-15 row adds, 16-19 patch
-    // loads, 20-27 column adds, 28-31 patch writes.  sched_barrier pins the order.
+    // the MFMAs (one piece behind each of MFMA 0..31): 0-3 filter-bank writes, 4-7 filter-bank
+    // loads, 8 border fix-up, 9 Bt d B (one burst), 10-13 patch writes, 16-19 patch loads; the
+    // operand reads of the next k-step ride behind the first three MFMAs of a k-step.  The
+    // hand-over barrier sits before MFMA 24 (start of the last k-step).  sched_barrier pins the
+    // order.
     f32x4 av[2][2], bv[2];
     auto run_chunk = [&](int cur, int chunk, auto store_c, auto load_c) {
         constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
@@ -324,7 +307,6 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                     }
                     if (STORE) {
                         if (p < 4) u_write(p, ldsb);
-#if STX_W2_BURST
                         // Bt d B as ONE burst of vector work: an isolated vector instruction
                         // between two MFMAs costs the matrix pipe ~13 cycles, the members of a
                         // burst ~4 each (tools/ubench/solo_issue.hip)
@@ -336,12 +318,6 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             for (int q = 0; q < 8; ++q) col_op(q);
                         }
                         if (p >= 10 && p < 14) v_write(p - 10, ldsb);
-#else
-                        if (p == 8) fix_edges();
-                        if (p >= 8 && p < 16) row_op(p - 8);
-                        if (p >= 20 && p < 28) col_op(p - 20);
-                        if (p >= 28) v_write(p - 28, ldsb);
-#endif
                     }
                     if (LOAD && !(STX_W2_SKIP & 1)) {
                         if (p >= 4 && p < 8) u_load(p - 4, ws);
@@ -367,20 +343,18 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     if (c_begin + 1 < c_end) load_stage(c_begin + 1);
     __syncthreads();
 
-    // Cycle counters (tools/ubench/wino2_bench.hip) put a chunk at ~4900 cycles against 4096 of
-    // pure matrix work: the SIMD arbitrates its pipe by age, the older wave of a pair runs at its
-    // own rate (64 cycles per MFMA + ~36 for its interleaved pieces: 3190 per chunk), the younger
-    // gets the gaps and runs its tail alone (4630).  s_setprio only swaps the roles; padding
-    // either or both waves with s_nop to one MFMA per 128 cycles, alternating priority per
-    // k-step, strict ping-pong with two barriers, and the barrier moved between k-steps 2 and 3
-    // were all measured and are no faster.  Neither is a persistent variant (workgroups drawing
-    // work items from a ticket counter, first loads of the next item issued before the epilogue
-    // of the current one): the ~6 us a workgroup spends outside its chunk loop are its own
-    // prologue and epilogue, not the ~2 us turnaround of a CU (tools/ubench/launch_gap.hip),
-    // which the dispatcher evidently overlaps.
+    // Cycle counters (tools/ubench/wino2_bench.hip -DSTX_WINO2_TIMING): a chunk takes ~4360 cycles
+    // of a SIMD against 4096 of pure matrix work (two waves x 32 MFMAs); the difference is the
+    // vector work of the two waves (never hidden behind fp32 MFMAs, tools/ubench/solo_issue.hip)
+    // and the hand-over.  Measured in round 1 and no faster: s_setprio (only swaps which wave of
+    // a pair runs ahead), padding with s_nop to one MFMA per 128 cycles, alternating priority
+    // per k-step, strict ping-pong with two barriers, a persistent variant (work items from a
+    // ticket counter, first loads of the next item issued before the epilogue of the current
+    // one: the ~4 us a workgroup spends outside its chunk loop are its own prologue and
+    // epilogue, not the ~2 us turnaround of a CU, tools/ubench/launch_gap.hip).
     int cur = 0;
     int chunk = c_begin;
-    long long t_work = 0, t_barrier = 0;
+    long long t_work = 0;
     STX_T(t_begin);
     // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
     // of the hand-over and of the operand reads is a register plus an immediate
@@ -669,7 +643,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #undef STX_PK_SUB
 #ifdef STX_WINO2_TIMING
     if (blockIdx.x == 0 && lane == 0) {
-        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = t_barrier;
+        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = 0;   // (the barrier is inside the chunk now)
         g_wino2_timing[wave][3] = t_main_end - t_begin;
         g_wino2_timing[wave][4] = t_begin - t_start;
         g_wino2_timing[wave][5] = clock64() - t_main_end;
