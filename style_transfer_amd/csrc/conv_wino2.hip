@@ -42,7 +42,7 @@ namespace stx {
 __device__ long long g_wino2_timing[8][8];
 #define STX_T(var) const long long var = clock64()
 #else
-#define STX_T(var) const long long var = 0
+#define STX_T(var) [[maybe_unused]] const long long var = 0
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // epilogue, not the ~2 us turnaround of a CU, tools/ubench/launch_gap.hip).
     int cur = 0;
     int chunk = c_begin;
-    long long t_work = 0;
+    [[maybe_unused]] long long t_work = 0;
     STX_T(t_begin);
     // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
     // of the hand-over and of the operand reads is a register plus an immediate
