@@ -332,6 +332,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
 
+    STX_T(t_loads);       // index setup done, first loads about to be issued
     load_stage(c_begin);
     // clear the accumulators while the first loads are in flight (left alone the compiler sinks the
     // 128 moves to just before the first MFMA, behind the barrier: ~1000 cycles of an idle pipe)
@@ -340,8 +341,9 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(acc[i][c]));
     store_stage(0);
+    STX_T(t_stored);      // first chunk landed, transformed and written to LDS
     if (c_begin + 1 < c_end) load_stage(c_begin + 1);
-    __syncthreads();
+    lds_barrier();        // (not __syncthreads(): that would wait for the loads just issued)
 
     // Cycle counters (tools/ubench/wino2_bench.hip -DSTX_WINO2_TIMING): a chunk takes ~4360 cycles
     // of a SIMD against 4096 of pure matrix work (two waves x 32 MFMAs); the difference is the
@@ -642,10 +644,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #undef STX_PK_ADD
 #undef STX_PK_SUB
 #ifdef STX_WINO2_TIMING
-    if (blockIdx.x == 0 && lane == 0) {
+    if (blockIdx.x == gridDim.x - 3 && lane == 0) {     // a workgroup of the last round
         g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = 0;   // (the barrier is inside the chunk now)
         g_wino2_timing[wave][3] = t_main_end - t_begin;
         g_wino2_timing[wave][4] = t_begin - t_start;
+        g_wino2_timing[wave][6] = t_loads - t_start, g_wino2_timing[wave][7] = t_stored - t_loads;
         g_wino2_timing[wave][5] = clock64() - t_main_end;
     }
 #endif

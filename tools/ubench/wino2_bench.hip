@@ -70,8 +70,8 @@ static void run(int K, int M, int H, int W, int epilogue) {
     hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
     const int chunks = (K + 7) / 8 - 2;
     for (int wv = 0; wv < 8; wv += 4)
-        printf("   wave %d: per chunk  work %6.0f  barrier %6.0f   |  prologue %6lld  chunk loop %7lld  epilogue %6lld cycles\n", wv,
-               (double)t[wv][0] / chunks, (double)t[wv][2] / chunks, t[wv][4], t[wv][3], t[wv][5]);
+        printf("   wave %d: per chunk  work %6.0f  |  prologue %6lld (setup %lld, loads -> LDS %lld)  chunk loop %7lld  last two chunks + epilogue %6lld cycles\n", wv,
+               (double)t[wv][0] / chunks, t[wv][4], t[wv][6], t[wv][7], t[wv][3], t[wv][5]);
 #endif
     hipFree(x), hipFree(y), hipFree(w), hipFree(mask);
 }
