@@ -215,6 +215,17 @@ int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, 
                            double p_scale, double p_power, const float *aux, double aux_scale,
                            const int aux_roll_xy[2], double *loss_out);
 
+/* The SWT term of eval_loss_and_grad (style_transfer.py:716-720, num_utils.py:179-196) for the
+ * reference's defaults --swt-wavelet haar --swt-levels 1:
+ *   D = detail part (approximation band zeroed) of the one-level stationary Haar transform of
+ *       roll(img)/127.5, taken on its symmetric padding to a power-of-two square and cropped back;
+ *   grad += scale * d p_norm(D, power) (the p-norm's own gradient at D, as the reference adds it);
+ *   *loss_out (host, written at stx_sync) = scale * sum |D|^power.
+ * roll_xy (or NULL): the iteration's shift; the image itself stays un-rolled.  PyWavelets is not
+ * part of the reference tree: the transform is restated (oracle/num_ops.py), parity unpinned. */
+int stx_image_swt_haar(stx_engine *e, const float *img, float *grad, int H, int W,
+                       const int roll_xy[2], double scale, double power, double *loss_out);
+
 /* AdamOptimizer.update after the gradient is known (optimizers.py:35-42), fused:
  *   g1 = b1*g1 + (1-b1)*grad; g2 = b2*g2 + (1-b2)*grad^2; p1 likewise on the new params;
  *   params -= lr * (g1/c1) / (sqrt(g2/c2) + EPS);  avg_out = p1/cp

@@ -67,3 +67,75 @@ def p_norm_loss_grad(x, p=2):
     a = np.abs(x)
     a1 = a ** np.float32(p - 1)
     return float(np.dot(a1.ravel(), a.ravel())), (np.float32(p) * np.sign(x) * a1).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------- SWT
+# num_utils.py:165-196: swt_norm(x, wavelet, level, p) pads every channel symmetrically to a square
+# of side 2**ceil(log2(max(H, W))), takes pywt.swt2, zeroes the approximation band, inverts with
+# pywt.iswt2, crops, and returns p_norm of the result (the gradient is the p-norm's gradient at
+# the detail image, NOT chained through the transform).  PyWavelets (pinned by nothing upstream:
+# `import pywt` at num_utils.py:9) is absent from /root/reference and from this image, so no
+# reference vectors exist: PARITY UNPINNED.  Restated for the defaults of the reference's command
+# line only ('haar', 1 level; config_system.py:84-87):
+#   * one level of the stationary (undecimated) Haar transform with periodic extension:
+#       a[n] = (x[n] + x[n+1]) / sqrt 2,  d[n] = (x[n] - x[n+1]) / sqrt 2   (every shift n)
+#   * its inverse averages the two reconstructions that a decimated transform would give from the
+#     even and from the odd shifts; with the approximation band zeroed what remains is the detail
+#     projector  x[n] - (x[n-1] + 2 x[n] + x[n+1]) / 4  per axis.  In 2-D only the low-low band is
+#     zeroed, so the detail image is  x - B x  with B = [1 2 1]/4 (rows) x [1 2 1]/4 (columns),
+#     circular on the padded square.
+# swt_haar1_filterbank below does the transform and its inverse band by band (no closed form) and
+# tests/test_oracle_swt.py holds the two against each other.
+
+def _pad_width(shape, divisors):
+    """num_utils.py:165-176."""
+    pw = []
+    for length, divisor in zip(shape, divisors):
+        to_pad = int(np.ceil(length / divisor)) * divisor - length
+        pw.append((to_pad // 2, to_pad // 2) if to_pad % 2 == 0 else (to_pad // 2, to_pad // 2 + 1))
+    return pw
+
+
+def swt_haar1_detail(x):
+    """Detail part (approximation band zeroed) of the one-level stationary Haar transform of every
+    channel of x [C,H,W], computed on the symmetric padding to a power-of-two square and cropped
+    back (num_utils.py:184-196 with wavelet='haar', level=1)."""
+    x = np.asarray(x, np.float32)
+    div = 2 ** int(np.ceil(np.log2(max(x.shape[1:]))))
+    pw = _pad_width(x.shape, (1, div, div))
+    xp = np.pad(x, pw, 'symmetric')
+    blur = xp
+    for axis in (1, 2):
+        blur = (np.roll(blur, 1, axis) + 2 * blur + np.roll(blur, -1, axis)) / np.float32(4)
+    d = xp - blur
+    return d[:, pw[1][0]:pw[1][0] + x.shape[1], pw[2][0]:pw[2][0] + x.shape[2]].astype(np.float32)
+
+
+def swt_haar1_filterbank(ch):
+    """The same for ONE square 2-D array, band by band: undecimated Haar analysis along both
+    axes, low-low band dropped, synthesis as the average over the shifts (float64)."""
+    ch = np.asarray(ch, np.float64)
+    s = np.sqrt(0.5)
+
+    def analysis(a, axis):
+        nxt = np.roll(a, -1, axis)
+        return s * (a + nxt), s * (a - nxt)
+
+    def synthesis(lo, hi, axis):
+        # x[n] from (lo[n], hi[n]) = s (x[n] +- x[n+1]) and from (lo[n-1], hi[n-1]); mean of both
+        from_n = s * (lo + hi)
+        from_prev = s * (np.roll(lo, 1, axis) - np.roll(hi, 1, axis))
+        return 0.5 * (from_n + from_prev)
+
+    lo, hi = analysis(ch, 0)
+    ll, lh = analysis(lo, 1)
+    hl, hh = analysis(hi, 1)
+    ll = np.zeros_like(ll)                       # coeffs[0][0][...] = 0  (num_utils.py:191-192)
+    lo_r = synthesis(ll, lh, 1)
+    hi_r = synthesis(hl, hh, 1)
+    return synthesis(lo_r, hi_r, 0)
+
+
+def swt_norm_haar1(x, p=2):
+    """(loss, grad) of num_utils.swt_norm(x, 'haar', 1, p)."""
+    return p_norm_loss_grad(swt_haar1_detail(x), p)

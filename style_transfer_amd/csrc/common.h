@@ -251,6 +251,9 @@ int roll_add_launch(hipStream_t s, float *acc, const float *src, int C, int h, i
                     float alpha, bool init);
 int resample_launch(hipStream_t s, int axis, const float *src, int C, int H, int W, float *dst,
                     int OH, int OW, const int *bounds, const double *k, int ksize, int clamp);
+int swt_haar_launch(hipStream_t s, const float *img, float *grad, int H, int W, int rx, int ry,
+                    float scale, float power, double *loss_term, float *scratch,
+                    size_t scratch_floats);
 int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int W,
                         const float mean[3], float tv_scale, float tv_power, float p_scale,
                         float p_power, const float *aux, float aux_scale, int aux_rx, int aux_ry,

@@ -1424,6 +1424,25 @@ int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, 
     return STX_OK;
 }
 
+int stx_image_swt_haar(stx_engine *e, const float *img, float *grad, int H, int W,
+                       const int roll_xy[2], double scale, double power, double *loss_out) {
+    if (!e || !img || !grad || H <= 0 || W <= 0 || power <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    size_t di;
+    STX_TRY(alloc_dscalars(e, 1, &di));
+    double *term = static_cast<double *>(e->dscalars.ptr) + di;
+    STX_TRY(swt_haar_launch(e->stream, img, grad, H, W, roll_xy ? roll_xy[0] : 0,
+                            roll_xy ? roll_xy[1] : 0, (float)scale, (float)power, term,
+                            e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
+    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, term, sizeof(double), hipMemcpyDeviceToHost,
+                           e->stream));
+    PendingLoss pl;
+    pl.out = loss_out;
+    pl.dterms.push_back(LossTerm{di, scale});
+    e->pending.push_back(std::move(pl));
+    return STX_OK;
+}
+
 int stx_adam_step(stx_engine *e, float *params, const float *grad, float *g1, float *g2, float *p1,
                   float *avg_out, size_t n, double lr, double b1, double b2, double bp1, double corr1,
                   double corr2, double corrp) {

@@ -313,6 +313,98 @@ int regularizers_launch(hipStream_t s, const float *img, float *grad, int H, int
     return STX_OK;
 }
 
+// ----------------------------------------------------------------------------------- SWT ---
+// The SWT regularizer of the reference for its defaults (wavelet 'haar', one level;
+// num_utils.py:179-196, style_transfer.py:716-720): every channel of img / 127.5 is padded
+// symmetrically to a square of side N = 2^ceil(log2(max(H, W))) (an odd amount puts the extra row
+// / column behind), transformed with the stationary Haar transform (periodic on the square), the
+// approximation band is dropped and the rest transformed back: what comes out is
+//     D = x - B x,   B = [1 2 1]/4 along rows x [1 2 1]/4 along columns, circular on the square
+// (oracle/num_ops.py has the derivation and a band-by-band check).  loss = sum |D|^p over the
+// H x W crop; the reference adds the p-norm's OWN gradient at D to the image gradient, not its
+// chain through D, and so does this.  The reference transforms the image rolled by the
+// iteration's shift; here the image stays un-rolled: pixel (y, x) sits at ((y + ry) mod H,
+// (x + rx) mod W) of the rolled picture.
+__device__ __forceinline__ int swt_source(int q, int pad_lo, int n) {
+    // padded coordinate q in [0, N) -> coordinate of the rolled picture (numpy.pad 'symmetric')
+    int t = (q - pad_lo) % (2 * n);
+    if (t < 0) t += 2 * n;
+    return t < n ? t : 2 * n - 1 - t;
+}
+
+__global__ __launch_bounds__(256) void swt_haar_kernel(const float *__restrict__ img,
+                                                       float *__restrict__ grad, int H, int W, int N,
+                                                       int rx, int ry, float scale, float power,
+                                                       float *__restrict__ partials) {
+    const size_t plane = (size_t)H * W, total = 3 * plane;
+    const int pad_y = (N - H) / 2, pad_x = (N - W) / 2;
+    float sums[1] = {0.f};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = i % W;
+        const int y = (i / W) % H;
+        const int c = i / plane;
+        const float *p = img + (size_t)c * plane;
+        // position in the rolled picture and on the padded square
+        int Y = (y + ry) % H, X = (x + rx) % W;
+        if (Y < 0) Y += H;
+        if (X < 0) X += W;
+        const int qy = Y + pad_y, qx = X + pad_x;
+        // rows first (vertical [1 2 1]/4), then columns, like the oracle's two passes
+        int uy[3];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int sy = swt_source((qy + dy + N) % N, pad_y, H);
+            uy[dy + 1] = (sy - ry) % H;
+            if (uy[dy + 1] < 0) uy[dy + 1] += H;
+        }
+        float cols[3], centre = 0.f;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int sx = swt_source((qx + dx + N) % N, pad_x, W);
+            int ux = (sx - rx) % W;
+            if (ux < 0) ux += W;
+            const float up = p[(size_t)uy[0] * W + ux] / 127.5f, mid = p[(size_t)uy[1] * W + ux] / 127.5f;
+            const float down = p[(size_t)uy[2] * W + ux] / 127.5f;
+            cols[dx + 1] = (up + 2.f * mid + down) / 4.f;
+            if (dx == 0) centre = mid;
+        }
+        const float blur = (cols[0] + 2.f * cols[1] + cols[2]) / 4.f;
+        const float d = centre - blur;
+        const float ad = fabsf(d);
+        float g;
+        if (power == 2.f) {
+            sums[0] += d * d;
+            g = 2.f * d;
+        } else if (power == 1.f) {
+            sums[0] += ad;
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else {
+            const float ap1 = powf(ad, power - 1.f);
+            sums[0] += ap1 * ad;
+            g = power * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * ap1;
+        }
+        grad[i] = scale * g + grad[i];
+    }
+    block_partials<1>(sums, partials);
+}
+
+int swt_haar_launch(hipStream_t s, const float *img, float *grad, int H, int W, int rx, int ry,
+                    float scale, float power, double *loss_term, float *scratch,
+                    size_t scratch_floats) {
+    int N = 1;
+    while (N < std::max(H, W)) N *= 2;
+    const int blocks = blocks_for((size_t)3 * H * W);
+    if (scratch_floats < (size_t)blocks) {
+        set_error("swt_haar: scratch too small");
+        return STX_ERR_STATE;
+    }
+    swt_haar_kernel<<<blocks, 256, 0, s>>>(img, grad, H, W, N, rx, ry, scale, power, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<1><<<1, 256, 0, s>>>(scratch, blocks, loss_term);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
 // ----------------------------------------------------------------------------------- Adam ---
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ params,
                                                    const float *__restrict__ grad,

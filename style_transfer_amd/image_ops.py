@@ -60,6 +60,18 @@ def regularizers(engine, img, grad, mean_bgr, tv_scale, tv_power, p_scale, p_pow
     return out
 
 
+def swt_haar(engine, img, grad, scale, power, roll=None):
+    """grad += scale * (p-norm gradient at the Haar SWT detail image of the rolled picture / 127.5);
+    returns a PendingScalar with scale * sum |detail|^power (style_transfer.py:716-720 for the
+    default wavelet and level count)."""
+    _, H, W = img.shape
+    out = PendingScalar()
+    lib.call('stx_image_swt_haar', engine.handle, img.ptr, grad.ptr, H, W,
+             _xy(roll) if roll is not None else None, float(scale), float(power),
+             ctypes.byref(out._v))
+    return out
+
+
 def adam_step(engine, params, grad, g1, g2, p1, avg, lr, b1, b2, bp1, corr1, corr2, corrp):
     lib.call('stx_adam_step', engine.handle, params.ptr, grad.ptr, g1.ptr, g2.ptr, p1.ptr, avg.ptr,
              params.size, float(lr), float(b1), float(b2), float(bp1), float(corr1), float(corr2),

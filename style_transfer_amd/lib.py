@@ -81,6 +81,7 @@ SIGNATURES = {
                            c_double_p, _i, _i],
     'stx_image_regularizers': [_vp, _vp, _vp, _i, _i, c_float_p, _d, _d, _d, _d, _vp, _d,
                                c_int_p, c_double_p],
+    'stx_image_swt_haar': [_vp, _vp, _vp, _i, _i, c_int_p, _d, _d, c_double_p],
     'stx_adam_step': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _d, _d, _d],
     'stx_vec_dot': [_vp, _vp, _vp, _sz, c_double_p],
     'stx_vec_axpy': [_vp, _d, _vp, _vp, _sz],

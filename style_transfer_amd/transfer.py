@@ -142,12 +142,14 @@ class StyleTransfer:
         self.current_raw = None     # DeviceArray: averaged iterate of the last step
         self.step = 0
         self.step_times = []
-        for name in ('swt_weight',):
-            # lazy (callable) values could turn non-zero mid-run: refuse them outright
-            raw = getattr(getattr(args, 'ns', args), name, 0)
-            if callable(raw) or raw:
-                raise NotImplementedError('--%s is outside the accelerated path '
-                                          '(reference default is off)' % name.replace('_', '-'))
+        # --swt-weight (style_transfer.py:716-720) calls PyWavelets, which is not part of the
+        # reference tree; its transform is restated for the command line's defaults only
+        raw = getattr(getattr(args, 'ns', args), 'swt_weight', 0)
+        if (callable(raw) or raw) and (str(args.swt_wavelet) not in ('haar', 'db1') or
+                                       int(args.swt_levels) != 1):
+            raise NotImplementedError('--swt-wavelet %s --swt-levels %s: only the default '
+                                      '(haar, 1 level) is implemented'
+                                      % (args.swt_wavelet, args.swt_levels))
 
     # ----------------------------------------------------------------------- image <-> params
     def pil_to_image(self, img):
@@ -236,6 +238,13 @@ class StyleTransfer:
                 lw * args.aux_weight if aux_on else 0.0, aux_roll=roll)
             self.engine.sync()
             loss += reg.value
+        if args.swt_weight:
+            # style_transfer.py:716-720.  Only the reference's default transform is restated
+            # (oracle/num_ops.py): PyWavelets, which it calls, is not part of its tree.
+            swt = image_ops.swt_haar(self.engine, params, self.grad, lw * args.swt_weight,
+                                     args.swt_power, roll=roll)
+            self.engine.sync()
+            loss += swt.value
         return loss, self.grad
 
     # --------------------------------------------------------------------------- one scale

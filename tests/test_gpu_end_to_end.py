@@ -222,3 +222,28 @@ def test_jitter_and_deep_dream_run_matches_reference(golden):
     print('jitter run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
     assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
     farm.close()
+
+
+def test_swt_weight_runs_and_adds_its_term(golden):
+    """--swt-weight with the default wavelet / level count (style_transfer.py:716-720): the run
+    goes through, and on the first evaluation -- same seed, so same start image and same shift --
+    the loss exceeds the run without it by the SWT term of that image (the term itself is held to
+    the oracle in tests/test_gpu_image_ops.py; PyWavelets is absent, so no reference run exists)."""
+    from argparse import Namespace
+    base = str(golden['e2e_aux.argv']).split()
+    losses = []
+    for extra in ([], ['--swt-weight', '3']):
+        state = Namespace()
+        args = parse_args(state, base + extra + ['-i', '2'], config_py=False)
+        net = builtin_net(args.model)
+        farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+        st = StyleTransfer(farm, args, state)
+        log = []
+        np.random.seed(args.seed)
+        st.transfer_multiscale([Image.fromarray(golden['e2e_aux.content_u8'])],
+                               [Image.fromarray(golden['e2e_aux.style_u8'])],
+                               callback=lambda **kw: log.append(kw['loss']))
+        losses.append(log)
+        farm.close()
+    assert all(np.isfinite(l) for run in losses for l in run)
+    assert losses[1][0] > losses[0][0]            # first evaluation: identical image, one more term

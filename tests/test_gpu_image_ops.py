@@ -151,3 +151,25 @@ def test_resample_is_bit_identical_to_pillow(hw, method):
     assert np.array_equal(got, ref)
     clamped = resample_device(eng, eng.to_device(a), hw, method, clamp_min_zero=True).get()
     assert np.array_equal(clamped, np.maximum(0, ref))
+
+
+@pytest.mark.parametrize('shape,roll,power', [((3, 16, 16), (0, 0), 2), ((3, 37, 53), (8, -16), 2),
+                                              ((3, 64, 20), (-24, 40), 1), ((3, 50, 44), (16, 8), 1.5)])
+def test_swt_haar_term_against_oracle(shape, roll, power):
+    """stx_image_swt_haar vs the oracle's restatement of num_utils.swt_norm(x, 'haar', 1, p) on the
+    picture rolled by the iteration's shift (PyWavelets is absent: the oracle itself is held to a
+    band-by-band transform in tests/test_oracle_swt.py; no reference vectors exist)."""
+    from oracle import num_ops
+    eng = gpu_engine('vgg19')
+    rng = np.random.RandomState(shape[1])
+    img = rng.uniform(-120, 130, shape).astype(np.float32)
+    g0 = rng.standard_normal(shape).astype(np.float32)
+    scale = 0.37
+    rolled = np.roll(img, (roll[1], roll[0]), (1, 2))          # roll = (x, y)
+    loss, grad = num_ops.swt_norm_haar1(rolled / np.float32(127.5), power)
+    want = g0 + np.float32(scale) * np.roll(grad, (-roll[1], -roll[0]), (1, 2))
+    d_img, d_grad = eng.to_device(img), eng.to_device(g0)
+    out = image_ops.swt_haar(eng, d_img, d_grad, scale, power, roll=roll)
+    eng.sync()
+    assert out.value == pytest.approx(scale * loss, rel=2e-5)
+    assert np.abs(d_grad.get() - want).max() <= 2e-5 * np.abs(want).max()

@@ -97,7 +97,8 @@ def test_synthetic_weights_agree_with_oracle():
 
 def test_unsupported_options_fail_loudly():
     from argparse import Namespace
-    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--swt-weight', '1'], config_py=False)
+    args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--swt-weight', '1', '--swt-wavelet', 'db2'],
+                                    config_py=False)
 
     class FakeFarm:
         master = None
