@@ -247,3 +247,32 @@ def test_swt_weight_runs_and_adds_its_term(golden):
         farm.close()
     assert all(np.isfinite(l) for run in losses for l in run)
     assert losses[1][0] > losses[0][0]            # first evaluation: identical image, one more term
+
+
+def test_style_multiscale_run_matches_reference(golden, capsys):
+    """--style-multiscale MIN MAX (style_transfer.py:493-531): the style Gram is the mean over a
+    sqrt(2) ladder of resamplings of the style picture -- here three (48, 68, 96) -- against the
+    reference's own transfer_multiscale run, the ladder it announced included."""
+    from argparse import Namespace
+    argv = str(golden['e2e_sm.argv']).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net(args.model)
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e_sm.content_u8'])],
+                           [Image.fromarray(golden['e2e_sm.style_u8'])],
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    printed = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Processing style')]
+    assert printed == str(golden['e2e_sm.style_lines']).splitlines()
+    ref, got = golden['e2e_sm.log'], np.float64(log)
+    assert got.shape == ref.shape
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-4), (got[:, 2], ref[:, 2])
+    assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-4)
+    diff = np.abs(st.current_raw.get() - golden['e2e_sm.final_raw'])
+    print('style-multiscale run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
+    assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
+    farm.close()
