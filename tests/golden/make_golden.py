@@ -462,6 +462,44 @@ def main():
     out['e2e_sm/style_lines'] = np.array('\n'.join(
         l for l in stdout.getvalue().splitlines() if l.startswith('Processing style')))
 
+    # ------- 4h. a run that leaves the defaults in many places at once: --init-image (the biased
+    # first-moment start of Adam, style_transfer.py:883-897), --style-scale, --div, --step-decay,
+    # --avg-window, --tv-power, --p-power, --mean, weighted non-default content / style layers.
+    # Two scales, 2 x 2 tiles at the second, Adam.
+    sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png', '--init-image', 'i.png',
+                '--style-scale', '0.75', '--div', '8', '--step-decay', '0.1', '0.6',
+                '--avg-window', '5', '--tv-power', '1.5', '--p-power', '4', '--tv-weight', '3',
+                '--mean', '100', '110', '120', '--content-layers', 'conv3_2', 'conv4_2:0.5',
+                '--style-layers', 'conv1_2', 'conv3_1:0.5', 'conv4_1', '--content-weight', '0.1',
+                '--size', '80', '--min-size', '56', '--tile-size', '48', '--iterations', '2', '3',
+                '--step-size', '10', '--display', 'none', '--seed', '51']
+    st.ARGS = config_system.parse_args(st.STATE)
+    st.STATS = st.StatLogger()
+    st.STATE.__dict__.clear()
+    # (the model and the workers get --mean the way style_transfer.py:1106-1110 hands it over)
+    model_args_h = (model_args[0], model_args[1], st.ARGS.mean, model_args[3])
+    st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+        make_sync_pool(st, model_args_h, 1, ref_pool_cls)
+    model = st.CaffeModel(*model_args_h, placeholder=True)
+    transfer = st.StyleTransfer(model)
+    content_u8 = smooth_image(100, 64, 80)
+    style_u8 = smooth_image(101, 72, 60)
+    init_u8 = smooth_image(102, 40, 50)
+    log = []
+    np.random.seed(st.ARGS.seed)
+    stdout = io.StringIO()
+    with contextlib.redirect_stdout(stdout):
+        transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                     Image.fromarray(init_u8), None, callback=Cb())
+    out['e2e_opts/content_u8'], out['e2e_opts/style_u8'], out['e2e_opts/init_u8'] = \
+        content_u8, style_u8, init_u8
+    out['e2e_opts/argv'] = np.array(' '.join(sys.argv[1:]))
+    out['e2e_opts/log'] = np.float64(log)
+    out['e2e_opts/final_raw'] = transfer.current_raw.copy()
+    out['e2e_opts/lines'] = np.array('\n'.join(
+        l for l in stdout.getvalue().splitlines()
+        if l.startswith(('Processing style', 'Scale ', 'Using '))))
+
     # ----------- 4d. the six deploy prototxts the reference ships, as parsed layer tuples (data
     # for the --model reader): (name, type, bottom, top, num_output, pad, kernel,
     # stride, pool).  Two independent readings must agree: the oracle's protobuf-text parser and

@@ -276,3 +276,38 @@ def test_style_multiscale_run_matches_reference(golden, capsys):
     print('style-multiscale run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
     assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
     farm.close()
+
+
+def test_many_options_run_matches_reference(golden, capsys):
+    """One reference run that leaves the defaults in many places at once: --init-image (Adam's
+    biased first-moment start, style_transfer.py:883-897), --style-scale, --div, --step-decay,
+    --avg-window, --tv-power 1.5, --p-power 4, --mean, weighted non-default content and style
+    layers; two scales, tiled."""
+    from argparse import Namespace
+    argv = str(golden['e2e_opts.argv']).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net(args.model)
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e_opts.content_u8'])],
+                           [Image.fromarray(golden['e2e_opts.style_u8'])],
+                           initial_image=Image.fromarray(golden['e2e_opts.init_u8']),
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    want = [l for l in str(golden['e2e_opts.lines']).splitlines() if l.startswith('Scale ')]
+    got_lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Scale ')]
+    assert got_lines == want
+    ref, got = golden['e2e_opts.log'], np.float64(log)
+    print(got, ref)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
+    assert np.allclose(got[:, 3], ref[:, 3], rtol=2e-4), (got[:, 3], ref[:, 3])
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3), (got[:, 1], ref[:, 1])
+    diff = np.abs(st.current_raw.get() - golden['e2e_opts.final_raw'])
+    print('many-options run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
+    assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
+    farm.close()
