@@ -500,6 +500,32 @@ def main():
         l for l in stdout.getvalue().splitlines()
         if l.startswith(('Processing style', 'Scale ', 'Using '))))
 
+    # ------- 4i. the remaining branches of the style-size rule (style_transfer.py:862-872):
+    # an absolute --style-scale (>= 32) and --max-style-size with --style-scale-up.  One scale,
+    # one tile, one Adam step each.
+    for tag, extra in (('abs', ['--style-scale', '48']),
+                       ('max', ['--style-scale', '2', '--max-style-size', '52', '--style-scale-up'])):
+        sys.argv = ['style_transfer.py', '-ci', 'c.png', '-si', 's.png'] + extra + [
+            '--size', '64', '--min-size', '64', '--tile-size', '64', '--iterations', '1',
+            '--display', 'none', '--seed', '61']
+        st.ARGS = config_system.parse_args(st.STATE)
+        st.STATS = st.StatLogger()
+        st.STATE.__dict__.clear()
+        st.TileWorkerPool = lambda model, devices, caffe_path=None: \
+            make_sync_pool(st, model_args, 1, ref_pool_cls)
+        model = st.CaffeModel(*model_args, placeholder=True)
+        transfer = st.StyleTransfer(model)
+        content_u8 = smooth_image(110, 56, 64)
+        style_u8 = smooth_image(111, 40, 44)
+        log = []
+        np.random.seed(st.ARGS.seed)
+        transfer.transfer_multiscale([Image.fromarray(content_u8)], [Image.fromarray(style_u8)],
+                                     None, None, callback=Cb())
+        out['e2e_ss/%s.argv' % tag] = np.array(' '.join(sys.argv[1:]))
+        out['e2e_ss/%s.log' % tag] = np.float64(log)
+        out['e2e_ss/%s.final_raw' % tag] = transfer.current_raw.copy()
+    out['e2e_ss/content_u8'], out['e2e_ss/style_u8'] = content_u8, style_u8
+
     # ----------- 4d. the six deploy prototxts the reference ships, as parsed layer tuples (data
     # for the --model reader): (name, type, bottom, top, num_output, pad, kernel,
     # stride, pool).  Two independent readings must agree: the oracle's protobuf-text parser and

@@ -311,3 +311,29 @@ def test_many_options_run_matches_reference(golden, capsys):
     print('many-options run: max %.3f mean %.5f' % (diff.max(), diff.mean()))
     assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
     farm.close()
+
+
+@pytest.mark.parametrize('tag', ['abs', 'max'])
+def test_style_size_rules_match_reference(golden, tag):
+    """The remaining branches of the style-size rule (style_transfer.py:862-872): an absolute
+    --style-scale (>= 32: fitted into that many pixels, scaled up if need be) and --max-style-size
+    with --style-scale-up, against the reference's own runs."""
+    from argparse import Namespace
+    argv = str(golden['e2e_ss.%s.argv' % tag]).split()
+    state = Namespace()
+    args = parse_args(state, argv, config_py=False)
+    net = builtin_net(args.model)
+    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+    st = StyleTransfer(farm, args, state)
+    log = []
+    np.random.seed(args.seed)
+    st.transfer_multiscale([Image.fromarray(golden['e2e_ss.content_u8'])],
+                           [Image.fromarray(golden['e2e_ss.style_u8'])],
+                           callback=lambda **kw: log.append(
+                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    ref, got = golden['e2e_ss.%s.log' % tag], np.float64(log)
+    assert got.shape == ref.shape
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-4), (got[:, 2], ref[:, 2])
+    diff = np.abs(st.current_raw.get() - golden['e2e_ss.%s.final_raw' % tag])
+    assert diff.mean() < 0.05 and np.percentile(diff, 99) < 0.5, (diff.max(), diff.mean())
+    farm.close()
