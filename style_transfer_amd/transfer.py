@@ -351,24 +351,26 @@ class StyleTransfer:
         # the current one (Pillow releases the interpreter lock inside resize; the main thread
         # sits in stx_sync most of the time): 0.1 s per 4096-pixel picture and level otherwise.
         pool = ThreadPoolExecutor(max_workers=1)
-        pending = pool.submit(resized, plans[0]) if plans else None
-        previous = None
-        for number, plan in enumerate(plans):
-            w, h = plan.content_wh
-            print('\nScale %d, image size %dx%d.\n' % (plan.index + 1, w, h))
-            contents, styles = pending.result()
-            pending = pool.submit(resized, plans[number + 1]) if number + 1 < len(plans) else None
-            if aux_image:
-                if self.aux_image is not None:
-                    self.aux_image.free()
-                self.aux_image = self.engine.to_device(
-                    self.pil_to_image(aux_image.resize((w, h), Image.LANCZOS)))
-            if previous is None:
-                self.optimizer = self._first_iterate(plan, initial_image)
-            else:
-                # model.resize_image (style_transfer.py:399-401): Lanczos, on the GPU
-                self.img = resample_device(self.engine, previous, (h, w))
-                self.optimizer.set_params(self.img)
-            previous = self.transfer(plan.iterations, contents, styles, callback)
-        pool.shutdown()
+        try:
+            pending = pool.submit(resized, plans[0]) if plans else None
+            previous = None
+            for number, plan in enumerate(plans):
+                w, h = plan.content_wh
+                print('\nScale %d, image size %dx%d.\n' % (plan.index + 1, w, h))
+                contents, styles = pending.result()
+                pending = pool.submit(resized, plans[number + 1]) if number + 1 < len(plans) else None
+                if aux_image:
+                    if self.aux_image is not None:
+                        self.aux_image.free()
+                    self.aux_image = self.engine.to_device(
+                        self.pil_to_image(aux_image.resize((w, h), Image.LANCZOS)))
+                if previous is None:
+                    self.optimizer = self._first_iterate(plan, initial_image)
+                else:
+                    # model.resize_image (style_transfer.py:399-401): Lanczos, on the GPU
+                    self.img = resample_device(self.engine, previous, (h, w))
+                    self.optimizer.set_params(self.img)
+                previous = self.transfer(plan.iterations, contents, styles, callback)
+        finally:
+            pool.shutdown()
         return self.current_output
