@@ -803,7 +803,8 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.pool_mode = p.pool_mode;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);
-    if (xb >= 2147483648.0 || wb >= 2147483648.0) {
+    const double yb = 4.0 * p.M * (double)p.H * p.W;       // the epilogue addresses the output planes
+    if (xb >= 2147483648.0 || wb >= 2147483648.0 || yb >= 2147483648.0) {   // through descriptors too
         set_error("wino2_launch: plane set exceeds the 2 GiB buffer-addressing limit");
         return STX_ERR_UNSUPPORTED;
     }
