@@ -5,6 +5,11 @@ Run in the build container only (it imports crowsonkb/style_transfer from /root/
 which does not exist on the GPU box):
 
     python tests/golden/make_golden.py
+    STX_GOLDEN_APPEND=e2e_sm python tests/golden/make_golden.py    # add one section's arrays only
+
+(A full regeneration reproduces the committed arrays to 1e-7 .. 5e-6 relative, not bit for bit --
+the thread order of the reference's multi-threaded BLAS calls -- so new sections are appended and
+the committed arrays stay as they were when the tests were tuned against them.)
 
 What executes unmodified from the reference: ``num_utils`` (scipy-BLAS helpers, TV / p-norm),
 ``optimizers`` (Adam, L-BFGS), ``config_system.parse_args`` and, from ``style_transfer``,
