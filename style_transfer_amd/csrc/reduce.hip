@@ -29,16 +29,45 @@ __global__ __launch_bounds__(256) void content_sums_kernel(const float *__restri
                                                            ContentWindow w,
                                                            float *__restrict__ partials) {
     __shared__ float red[2][4];
-    const size_t total = (size_t)w.C * w.fh * w.fw;
-    float sq = 0.f, ab = 0.f;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = i % w.fw;
-        const int y = (i / w.fw) % w.fh;
-        const int c = i / ((size_t)w.fw * w.fh);
-        const float d = feat[i] - (content ? content[content_index(w, c, y, x)] : 0.f);   // null map: Deep Dream
-        sq += d * d;
-        ab += fabsf(d);
+    // One wave per 64-column segment of a feature row: the wrapped row / first column of the
+    // content map are wave-uniform and computed once per segment (per ELEMENT, with its 64-bit
+    // divisions, this kernel took 38 us for the 33 MB of conv4_2 where the two streams it reads
+    // need 13).  Segments are dealt out in a fixed order: the sums do not depend on timing.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int segs = (w.fw + 63) >> 6;
+    const int total_segs = w.C * w.fh * segs;
+    int x_first = (w.ox - w.sx) % w.cw;
+    if (x_first < 0) x_first += w.cw;
+    // four segments per trip: eight loads in flight per lane (with one segment per trip the kernel
+    // was bound by load latency: 2 MB in flight on the whole chip)
+    float sq4[4] = {0.f, 0.f, 0.f, 0.f}, ab4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int step = gridDim.x * 4;
+    for (int g0 = blockIdx.x * 4 + wave; g0 < total_segs; g0 += 4 * step) {
+        float f[4], t[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + u * step;
+            const int gg = g < total_segs ? g : g0;
+            const int row = gg / segs, x0 = (gg - row * segs) * 64;
+            const int c = row / w.fh, y = row - c * w.fh;
+            int yy = (w.oy + y - w.sy) % w.ch;
+            if (yy < 0) yy += w.ch;
+            const int x = x0 + lane;
+            ok[u] = g < total_segs && x < w.fw;
+            const int xc = x < w.fw ? x : 0;
+            const int xx = (x_first + xc) % w.cw;
+            f[u] = feat[((size_t)c * w.fh + y) * w.fw + xc];
+            t[u] = content ? content[((size_t)c * w.ch + yy) * w.cw + xx] : 0.f;   // null map: Deep Dream
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d = ok[u] ? f[u] - t[u] : 0.f;
+            sq4[u] += d * d;
+            ab4[u] += fabsf(d);
+        }
     }
+    float sq = (sq4[0] + sq4[1]) + (sq4[2] + sq4[3]), ab = (ab4[0] + ab4[1]) + (ab4[2] + ab4[3]);
     sq = wave_sum(sq);
     ab = wave_sum(ab);
     if ((threadIdx.x & 63) == 0) {
