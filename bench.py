@@ -13,11 +13,14 @@ HIP streams of the GPU), stitch, TV + p-norm regularizers, fused Adam step with 
 step statistics.  Everything is resident in HBM when the timed region starts.  Synthetic data:
 seeded He-initialised VGG-19 weights, seeded low-pass-noise content and style pictures (no network).
 
-N > 1 is weak scaling: every rank evaluates four 1024 x 1024 tiles per step and the image grows
-with N (2048 x 4096, 4096 x 4096 -- config 4's top scale -- and 4096 x 8192 at N = 2, 4, 8); rank 0
-owns the image and the optimizer, tiles go out and gradients come back as batched point-to-point
-transfers over RCCL, there is no collective on the data path.  value = tile-iterations per second
-of the whole job.
+At N = 1 the step loop runs through TileFarm, the product's own driver.  N > 1 is weak scaling:
+every rank evaluates four 1024 x 1024 tiles per step and the image grows with N (2048 x 4096,
+4096 x 4096 -- config 4's top scale -- and 4096 x 8192 at N = 2, 4, 8); rank 0 owns the image and
+the optimizer, tiles go out and gradients come back as batched point-to-point transfers over RCCL,
+there is no collective on the data path.  value = tile-iterations per second of the whole job.
+north_star's layout -- ONE host process driving all N GPUs through TileFarm (tiles and gradients
+as xGMI peer copies ordered by events, no host wait inside a step) -- is timed on the same image
+and step loop after the ranks have finished, and reported as the `farm` sub-record.
 
 The line also carries
   roofline      the matrix-core work the kernels ISSUE for the four tile-iterations of one GPU
@@ -67,7 +70,7 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
-TRAFFIC_PROFILE = 'profiles/r02_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE = 'profiles/r03_hbm_traffic_pmc.json'
 
 
 def measured_traffic():
@@ -111,6 +114,82 @@ def cpu_baseline(net):
                       % (reps, size, size, dt)}
 
 
+class FarmJob:
+    """The benchmark's step loop on a TileFarm over `devices` (one host process): image of
+    rows x cols tiles of 1024 x 1024, targets computed on the master GPU, Adam."""
+
+    def __init__(self, net, weights, devices, rows, cols):
+        from style_transfer_amd import image_ops
+        from style_transfer_amd.farm import TileFarm
+        from style_transfer_amd.optimizers import AdamOptimizer
+        self.image_ops = image_ops
+        self.H, self.W = rows * TILE, cols * TILE
+        self.farm = TileFarm(net, list(devices), weights, verbose=False,
+                             streams_per_device=TILES_PER_GPU)
+        eng = self.eng = self.farm.master
+        style_feats = self.farm.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS,
+                                                        TILE, passes=1)
+        styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
+        contents = [self.farm.prepare_features_device(smooth_picture(8, self.H, self.W),
+                                                      CONTENT_LAYERS, TILE, passes=1)]
+        self.farm.set_contents_and_styles(contents, styles)
+        self.content_weight = {'conv4_2': 0.05}
+        self.style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
+        rng = np.random.RandomState(0)
+        # the reference's start image: uniform noise minus the mean (style_transfer.py:889)
+        self.img = eng.to_device(rng.uniform(0, 255, (3, self.H, self.W)).astype(np.float32) -
+                                 np.float32(MEAN).reshape(3, 1, 1))
+        self.grad = eng.empty((3, self.H, self.W))
+        self.old = eng.empty((3, self.H, self.W)).copy_from(self.img)
+        self.rng = np.random.RandomState(0)
+        self.opt = AdamOptimizer(eng, self.img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
+        self.group_ms = []
+        self.tiles_per_step = rows * cols
+
+    def step(self):
+        """One iteration of the reference's step loop (style_transfer.py:771-815); one host
+        synchronisation, for the step statistics."""
+        xy = np.int32(self.rng.uniform(-0.5, 0.5, size=2) * (self.H, self.W)) // 8
+        roll = xy * 8
+
+        def opfunc(params):
+            loss = self.farm.eval_sc_grad(params, self.grad, roll, CONTENT_LAYERS, STYLE_LAYERS, {},
+                                          self.content_weight, self.style_weight, TILE, lazy=True)
+            loss.add(self.image_ops.regularizers(self.eng, params, self.grad, MEAN, 5.0, 2.0, 2.0,
+                                                 6.0), self.eng)
+            return loss, self.grad
+        avg, loss = self.opt.update(opfunc)
+        self.image_ops.step_stats(self.eng, avg, self.old)
+        loss = float(loss)
+        self.group_ms.append(max(e.last_tile_ms() for e in self.farm.engines[:self.tiles_per_step]))
+        return loss
+
+    def fence(self):
+        for e in self.farm.engines:
+            e.sync()
+
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.group_ms.clear()
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(steps):
+            loss = self.step()
+        self.fence()
+        return time.perf_counter() - t0, loss
+
+    def graph_counters(self):
+        from style_transfer_amd import lib
+        return {'captures': sum(e.query(lib.Q_GRAPH_CAPTURES) for e in self.farm.engines),
+                'replays': sum(e.query(lib.Q_GRAPH_REPLAYS) for e in self.farm.engines),
+                'eager': sum(e.query(lib.Q_EAGER_TILES) for e in self.farm.engines)}
+
+    def close(self):
+        self.farm.close()
+
+
 def whole_run_wall_clock(devices):
     """Wall-clock of the reference's command line for the metric's configuration, start to finish:
     `--size 2048 --tile-size 1024`, Adam, default iterations (200 + 6 x 100 over 7 scales = 1400
@@ -138,7 +217,7 @@ def whole_run_wall_clock(devices):
             '--devices'] + [str(d) for d in devices]
     t0 = time.perf_counter()
     proc = subprocess.run([sys.executable, os.path.join(REPO, 'style_transfer.py')] + args, cwd=tmp,
-                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
     outer = time.perf_counter() - t0
     lines = proc.stdout.splitlines()
     if proc.returncode != 0:
@@ -153,6 +232,40 @@ def whole_run_wall_clock(devices):
             'wall_clock_summary': summary}
 
 
+def roofline_record(eng, avg_group_ms):
+    """Matrix-core work issued by one GPU's four concurrent tile evaluations over their HIP-event
+    span, against the fp32 MFMA peak."""
+    flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
+    direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
+    # what the kernels actually put on the matrix cores: the 3x3 layers run Winograd kernels
+    # that issue 4/9 (2-D) or 2/3 (1-D) of the direct-convolution MFMAs; Gram / SYMM in full
+    conv_alg, conv_issued = eng.last_tile_flops()
+    issued = (flop / TILES_PER_GPU - conv_alg + conv_issued) * TILES_PER_GPU
+    issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
+    bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+    traffic, traffic_src = measured_traffic()
+    return {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
+            'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / TILES_PER_GPU,
+            'traffic': traffic, 'traffic_unit': 'bytes per launch',
+            'traffic_source': traffic_src,
+            'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_wino2_kernel<0|1|3,32> '
+                      '(3x3 layers forward / backward / loss-injecting backward; dominant), '
+                      'conv_mfma_kernel (first layer, SYMM), conv3x3_m4_kernel (backward into the '
+                      'image), gram_partial_* / gram_finish_kernel' % TILES_PER_GPU,
+            'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
+            'achieved_direct_equiv': direct_equiv,
+            'flop_direct_equiv_per_launch': flop,
+            'note': 'achieved / frac = matrix-core FLOP actually issued (Winograd '
+                    'F(2x2,3x3) convolutions issue 4/9 of a direct convolution, Gram '
+                    'and SYMM in full) over the HIP-event time of the launch group, '
+                    'against the fp32 MFMA peak at 2.4 GHz; achieved_direct_equiv '
+                    'credits every convolution as a direct one (SURVEY 8d: 1 514 240 '
+                    'FLOP per tile pixel) and is not a roofline fraction; traffic is '
+                    'a replay of the committed PMC profile named in traffic_source, '
+                    'not a measurement of this run'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -161,6 +274,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-wall-clock', action='store_true',
                     help='skip the whole-run wall-clock leg (about 10 s)')
+    ap.add_argument('--no-farm-leg', action='store_true',
+                    help='N > 1: skip the single-host-process (TileFarm) measurement')
     ap.add_argument('--steady-seconds', type=float, default=5.0)
     ap.add_argument('--debug-grid', default=None,
                     help='RxC tile grid instead of the one for --gpus (tests only: lets a single '
@@ -187,30 +302,106 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo' if debug_one_gpu else 'nccl', rank=rank, world_size=world)
 
+    from style_transfer_amd.netspec import builtin_net
+    from style_transfer_amd.weights import synthetic_weights
+    net = builtin_net('vgg19')
+    rows, cols = GRIDS[world] if not opts.debug_grid else \
+        tuple(int(v) for v in opts.debug_grid.split('x'))
+
+    if world == 1:
+        line = bench_single(opts, net, synthetic_weights(net, 0), local_rank, rows, cols)
+    else:
+        line = bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_one_gpu)
+    if rank != 0:
+        return
+    devices = list(range(world)) if not debug_one_gpu else [0]
+    if world > 1 and not opts.no_farm_leg and not debug_one_gpu:
+        # north_star's layout on the same image and step loop: one host process, N GPUs.  The
+        # other ranks have left (their process group is gone, their engines are closed).
+        try:
+            job = FarmJob(net, synthetic_weights(net, 0), devices, rows, cols)
+            elapsed, loss = job.timed(opts.steps, opts.warmup)
+            line['farm'] = {'layout': 'one host process, TileFarm over %d GPUs (xGMI peer copies, '
+                                      'event-ordered, no host wait inside a step)' % world,
+                            'value': job.tiles_per_step * opts.steps / elapsed,
+                            'unit': 'tile-iterations/s', 'ms_per_step': elapsed / opts.steps * 1e3,
+                            'steps': opts.steps, 'final_loss': loss,
+                            'avg_launch_ms': float(np.mean(job.group_ms)),
+                            'graphs': job.graph_counters()}
+            job.close()
+        except Exception as err:      # pylint: disable=broad-except
+            line['farm'] = {'error': '%s: %s' % (type(err).__name__, err)}
+    if not opts.no_wall_clock and not debug_one_gpu:
+        # the whole command-line run on this job's GPUs, one host process
+        try:
+            line.update(whole_run_wall_clock(devices))
+        except Exception as err:      # pylint: disable=broad-except
+            line['wall_clock_s'] = None
+            line['wall_clock_error'] = '%s: %s' % (type(err).__name__, err)
+    if world == 1 and not opts.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(net)
+    print(json.dumps(line), flush=True)
+
+
+def base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms):
+    H, W = rows * TILE, cols * TILE
+    tiles_per_step = rows * cols
+    return {
+        'metric': 'tile-iterations/sec, VGG-19 2048px/1024-tile (fwd+bwd, Gram/content losses, '
+                  'regularizers, Adam step)',
+        'value': tiles_per_step * opts.steps / elapsed,
+        'unit': 'tile-iterations/s',
+        'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
+        'ms_per_step': elapsed / opts.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tiles of '
+                               '%dx%d per step, %d per GPU' % (max(H, W), TILE, W, H, tiles_per_step,
+                                                             TILE, TILE, TILES_PER_GPU),
+                   'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
+                   'tiles_per_step': tiles_per_step, 'tiles_per_gpu': TILES_PER_GPU,
+                   'final_loss': loss},
+        'roofline': roofline_record(eng, float(np.mean(timed_group_ms))),
+    }
+
+
+def bench_single(opts, net, weights, device_index, rows, cols):
+    """N = 1: the step loop through TileFarm (four engines = four HIP streams on the GPU)."""
+    job = FarmJob(net, weights, [device_index], rows, cols)
+    elapsed, loss = job.timed(opts.steps, opts.warmup)
+    timed_group_ms = list(job.group_ms)
+    line = base_line(opts, 1, rows, cols, elapsed, loss, job.eng, timed_group_ms)
+    if opts.steady_seconds > 0:
+        n_steady = max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))
+        dt, _ = job.timed(n_steady, 0)
+        line['steady'] = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
+                          'value': job.tiles_per_step * n_steady / dt, 'unit': 'tile-iterations/s'}
+    line['graphs'] = job.graph_counters()
+    job.close()
+    return line
+
+
+def bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_one_gpu):
+    """N > 1: one process per GPU under torch.distributed.run.  Returns the line on rank 0."""
+    import torch
+    import torch.distributed as dist
     from style_transfer_amd import image_ops
+    from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
     from style_transfer_amd.engine import DeviceArray, TileEngine
     from style_transfer_amd.farm import TileFarm, tile_grid
-    from style_transfer_amd.netspec import builtin_net
     from style_transfer_amd.optimizers import AdamOptimizer
     from style_transfer_amd.weights import synthetic_weights
 
-    net = builtin_net('vgg19')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo' if debug_one_gpu else 'nccl', rank=rank, world_size=world)
     # weights: built once on rank 0 and broadcast with ONE RCCL collective (80 MB); every other
     # rank sets its engines from the received device tensors
-    weights = synthetic_weights(net, 0) if rank == 0 else None
-    if world > 1:
-        from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
-        weights = broadcast_weights(weights, device)
-    # every rank: TILES_PER_GPU engines (HIP streams) on its GPU, one tile of the step each
-    engines = [TileEngine(net, local_rank, weights) for _ in range(TILES_PER_GPU)]
+    weights = broadcast_weights(synthetic_weights(net, 0) if rank == 0 else None, device)
+    # every rank: TILES_PER_GPU engines (HIP streams) on its GPU sharing one weight bank and one
+    # target set, one tile of the step each
+    engines = [TileEngine(net, local_rank, weights)]
+    engines += [TileEngine(net, local_rank, share=engines[0]) for _ in range(TILES_PER_GPU - 1)]
     eng = engines[0]
-    rows, cols = GRIDS[world] if not opts.debug_grid else \
-        tuple(int(v) for v in opts.debug_grid.split('x'))
     H, W = rows * TILE, cols * TILE
     rects = tile_grid((H, W), TILE)
     assert len(rects) % world == 0 and (opts.debug_grid or len(rects) == TILES_PER_GPU * world)
@@ -228,11 +419,9 @@ def main():
         styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
         contents = [helper.prepare_features_device(smooth_picture(8, H, W), CONTENT_LAYERS, TILE,
                                                    passes=1)]
-    if world > 1:
-        contents, styles = broadcast_targets(contents, styles, device)
-    for e in engines:
-        e.set_contents_and_styles(contents, styles)
-        e.sync()
+    contents, styles = broadcast_targets(contents, styles, device)
+    eng.set_contents_and_styles(contents, styles)          # (the rank's other engines share them)
+    eng.sync()
 
     def wrap(tensor, engine):
         """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
@@ -242,25 +431,25 @@ def main():
     state = {}
     if rank == 0:
         rng = np.random.RandomState(0)
-        # the reference's start image: uniform noise minus the mean (style_transfer.py:889)
         img = eng.to_device(rng.uniform(0, 255, (3, H, W)).astype(np.float32) -
                             np.float32(MEAN).reshape(3, 1, 1))
         state.update(img=img, grad=eng.empty((3, H, W)),
                      old=eng.empty((3, H, W)).copy_from(img), rng=np.random.RandomState(0),
                      opt=AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05,
                                        power=0.5))
-
     inflight = []
+    grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
+                 for _ in range(tiles_per_rank)]
+    tile_bufs = {}
 
     def evaluate_begin(jobs, roll):
         """Enqueues this rank's tiles, one per engine (they run concurrently)."""
         inflight.clear()
         for k, (tile, start) in enumerate(jobs):
             e = engines[k % len(engines)]
-            g = grad_bufs[k]
             inflight.append((e, k, e.sc_grad_tile_async(
                 wrap(tile, e), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {}, content_weight,
-                style_weight, grad_out=wrap(g, e))))
+                style_weight, grad_out=wrap(grad_bufs[k], e))))
 
     def evaluate_end():
         """Waits for them; [(loss, grad tensor)]."""
@@ -273,14 +462,6 @@ def main():
         group_ms.append(max(e.last_tile_ms() for e in used))
         return [(p.loss, grad_bufs[k]) for _, k, p in inflight]
 
-    def evaluate(jobs, roll):
-        evaluate_begin(jobs, roll)
-        return evaluate_end()
-
-    grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
-                 for _ in range(tiles_per_rank)]
-    tile_bufs = {}
-
     def cut(rect, roll):
         if rect not in tile_bufs:
             tile_bufs[rect] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
@@ -291,19 +472,8 @@ def main():
     def put(rect, g, roll):
         image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g, eng))
 
-    if world > 1:
-        farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0],
-                                (evaluate_begin, evaluate_end), put, device)
-
-    def eval_sc_grad(roll):
-        if world > 1:
-            return farm.eval_sc_grad(rects, roll)
-        tiles = [cut(rect, roll) for rect in rects]
-        eng.sync()
-        results = evaluate([(t, (r[0], r[2])) for t, r in zip(tiles, rects)], roll)
-        for rect, (_, g) in zip(rects, results):
-            put(rect, g, roll)
-        return sum(l for l, _ in results)
+    farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0],
+                            (evaluate_begin, evaluate_end), put, device)
 
     def step():
         if rank != 0:
@@ -313,7 +483,7 @@ def main():
         roll = xy * 8
 
         def opfunc(params):
-            loss = eval_sc_grad(roll)
+            loss = farm.eval_sc_grad(rects, roll)
             reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
             eng.sync()
             return loss + reg.value, state['grad']
@@ -325,10 +495,10 @@ def main():
         for e in engines:
             e.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
+    wire = 'cpu' if debug_one_gpu else device
     loss = None
     for _ in range(opts.warmup):
         step()
@@ -339,20 +509,18 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if debug_one_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
     timed_group_ms = list(group_ms)
 
     # ---- a second, longer measurement of the same loop (the timed region above is short)
     steady = None
     if opts.steady_seconds > 0:
-        n_steady = max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))
-        if world > 1:
-            t = torch.tensor([n_steady], dtype=torch.int64, device='cpu' if debug_one_gpu else device)
-            dist.broadcast(t, 0)
-            n_steady = int(t[0])
+        t = torch.tensor([max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))],
+                         dtype=torch.int64, device=wire)
+        dist.broadcast(t, 0)
+        n_steady = int(t[0])
         fence()
         t1 = time.perf_counter()
         for _ in range(n_steady):
@@ -361,74 +529,18 @@ def main():
         dt = time.perf_counter() - t1
         steady = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
                   'value': len(rects) * n_steady / dt, 'unit': 'tile-iterations/s'}
-
+    line = None
     if rank == 0:
-        ms_per_step = elapsed / opts.steps * 1e3
-        tiles_per_step = len(rects)
-        avg_group_ms = float(np.mean(timed_group_ms))
-        flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
-        direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
-        # what the kernels actually put on the matrix cores: the 3x3 layers run Winograd kernels
-        # that issue 4/9 (2-D) or 2/3 (1-D) of the direct-convolution MFMAs; Gram / SYMM in full
-        conv_alg, conv_issued = eng.last_tile_flops()
-        issued = (flop / TILES_PER_GPU - conv_alg + conv_issued) * TILES_PER_GPU
-        issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
-        bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
-        traffic, traffic_src = measured_traffic()
-        line = {
-            'metric': 'tile-iterations/sec, VGG-19 2048px/1024-tile (fwd+bwd, Gram/content losses, '
-                      'regularizers, Adam step)',
-            'value': tiles_per_step * opts.steps / elapsed,
-            'unit': 'tile-iterations/s',
-            'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tiles of '
-                                   '%dx%d per step, %d per GPU' % (max(H, W), TILE, W, H, tiles_per_step,
-                                                                 TILE, TILE, TILES_PER_GPU),
-                       'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
-                       'tiles_per_step': tiles_per_step, 'tiles_per_gpu': TILES_PER_GPU,
-                       'final_loss': loss},
-            'roofline': {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
-                         'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / TILES_PER_GPU,
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch',
-                         'traffic_source': traffic_src,
-                         'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU (conv_wino4_kernel / '
-                                   'conv_wino2_kernel fwd + dgrad, conv_mfma_kernel first layer + '
-                                   'SYMM, gram)' % TILES_PER_GPU,
-                         'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
-                         'achieved_direct_equiv': direct_equiv,
-                         'flop_direct_equiv_per_launch': flop,
-                         'note': 'achieved / frac = matrix-core FLOP actually issued (Winograd '
-                                 'F(2x2,3x3) convolutions issue 4/9 of a direct convolution, Gram '
-                                 'and SYMM in full) over the HIP-event time of the launch group, '
-                                 'against the fp32 MFMA peak at 2.4 GHz; achieved_direct_equiv '
-                                 'credits every convolution as a direct one (SURVEY 8d: 1 514 240 '
-                                 'FLOP per tile pixel) and is not a roofline fraction; traffic is '
-                                 'a replay of the committed PMC profile named in traffic_source, '
-                                 'not a measurement of this run'},
-        }
+        line = base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms)
         if steady is not None:
             line['steady'] = steady
-        if not opts.no_wall_clock and not debug_one_gpu:
-            # the whole command-line run on this job's GPUs, one host process (the other ranks
-            # wait at the barrier below)
-            for e in engines:
-                e.sync()
-            try:
-                line.update(whole_run_wall_clock(list(range(world))))
-            except Exception as err:      # pylint: disable=broad-except
-                line['wall_clock_s'] = None
-                line['wall_clock_error'] = '%s: %s' % (type(err).__name__, err)
-        if world == 1 and not opts.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(net)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # every rank lets go of its GPU before rank 0 goes on alone (farm and whole-run legs drive
+    # all GPUs from one process); no collective is pending past this point
+    dist.barrier()
+    dist.destroy_process_group()
     for e in engines:
         e.close()
+    return line
 
 
 if __name__ == '__main__':

@@ -77,12 +77,35 @@ int stx_device_name(int device, char *buf, size_t buf_len);
 /* Replaces TileWorker.run's setup (style_transfer.py:187-207: pick device, caffe.Net(deploy, 1,
  * weights)).  The graph is copied.  Weights are supplied separately with stx_set_conv_weights. */
 int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, stx_engine **out);
+/* Another worker on the primary's GPU: its own HIP stream and activation buffers, but the
+ * primary's network, weights, packed filter banks and targets (one copy per GPU).  The reference
+ * gives every TileWorker process its own caffe.Net (style_transfer.py:187-207) and sends the
+ * targets to each (style_transfer.py:309-332); engines created here see what is set through any
+ * engine of the group -- stx_set_conv_weights / stx_set_contents_and_styles need to be called
+ * once per GPU. */
+int stx_engine_create_shared(stx_engine *primary, stx_engine **out);
 void stx_engine_destroy(stx_engine *e);
 /* Caffe blob layout: weights [Cout][Cin][k][k], bias [Cout], float32 (Appendix C of SURVEY.md). */
 int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *weights,
                          const float *bias, int mem);
 /* Waits for all work queued on the engine, then writes pending loss values. */
 int stx_sync(stx_engine *e);
+/* Orders e's stream behind everything queued so far on other's stream (an event; no host wait).
+ * The engines may sit on different GPUs.  This is what replaces the reference's blocking
+ * resp_q.get() between handing out tiles and stitching their gradients (style_transfer.py:
+ * 634-643): the master's stream waits for a worker's gradient, the host does not. */
+int stx_engine_wait(stx_engine *e, stx_engine *other);
+/* Counters for tests and bench.py. */
+typedef enum stx_query {
+    STX_Q_SHARED_ENGINES = 0,  /* engines sharing this engine's weights / targets (>= 1) */
+    STX_Q_TARGET_UPLOADS = 1,  /* stx_set_contents_and_styles calls served by this group */
+    STX_Q_TARGET_BYTES = 2,    /* bytes those calls copied, cumulative */
+    STX_Q_WEIGHT_BYTES = 3,    /* device bytes of weights + packed banks held by this group */
+    STX_Q_GRAPH_CAPTURES = 4,  /* tile evaluations recorded as launch graphs by this engine */
+    STX_Q_GRAPH_REPLAYS = 5,   /* tile evaluations served by replaying a recording */
+    STX_Q_EAGER_TILES = 6      /* tile evaluations enqueued kernel by kernel */
+} stx_query;
+int stx_engine_query(stx_engine *e, int what, double *value);
 int stx_engine_device(stx_engine *e, int *device);
 /* The engine's hipStream_t as an opaque pointer (for callers that enqueue their own copies). */
 int stx_engine_stream(stx_engine *e, void **hip_stream);

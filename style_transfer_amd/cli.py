@@ -5,15 +5,16 @@ PNG comment block (``style_transfer.py:1003-1010``).  The web / GUI live views a
 the accelerated path; ``--display`` is accepted and ignored.
 """
 
+from concurrent.futures import ThreadPoolExecutor
 import csv
 from datetime import datetime
 import sys
 import time
 
 import numpy as np
-from PIL import Image, PngImagePlugin
+from PIL import Image
 
-from . import lib
+from . import fastpng, image_ops, lib
 from .config_system import parse_args
 from .farm import TileFarm
 from .netspec import load_net
@@ -52,6 +53,15 @@ class Progress:
     def __init__(self, run, stats, save_every=0):
         self.run, self.stats, self.save_every = run, stats, save_every
         self.prev_t, self.step, self.steps = None, 0, 0
+        self.writer = ThreadPoolExecutor(max_workers=1) if save_every else None
+        self.writes = []
+
+    def finish(self):
+        """Waits for the --save-every pictures still being encoded."""
+        for w in self.writes:
+            w.result()
+        if self.writer is not None:
+            self.writer.shutdown()
 
     def set_steps(self, steps):
         self.steps = steps
@@ -66,7 +76,10 @@ class Progress:
                            content_w=transfer.img.shape[2])
         self.stats.update(update_size=update_size, loss=loss, tv_norm=tv_loss)
         if self.save_every and self.step % self.save_every == 0:
-            transfer.current_output.save(self.run + '_out_%04d.png' % self.step)
+            # the pixels leave the GPU now; deflate and file I/O run beside the next steps
+            rgb = image_ops.to_u8(transfer.engine, transfer.current_raw, transfer.mean)
+            self.writes.append(self.writer.submit(fastpng.save_rgb,
+                                                  self.run + '_out_%04d.png' % self.step, rgb))
         print('Step %d, time: %.2f s, update: %.2f, loss: %e, tv: %.2f' %
               (step, dt, update_size, loss, tv_loss), flush=True)
 
@@ -120,13 +133,18 @@ def main(argv=None):
         print()
     finally:
         stats.dump(run + '_log.csv')
-    output = transfer.current_output
-    if output is not None:
+        progress.finish()
+    if transfer.current_raw is not None:
         path = args.output_image or run + '_out.png'
         print('Saving output as %s.' % path)
-        info = PngImagePlugin.PngInfo()
-        info.add_itxt('Comment', image_comment(args, argv))
-        output.save(path, pnginfo=info)
+        rgb = image_ops.to_u8(transfer.engine, transfer.current_raw, transfer.mean)
+        comment = [('Comment', image_comment(args, argv))]
+        if path.lower().endswith('.png'):
+            # the reference's image.save(path, pnginfo=...) (style_transfer.py:1003-1010): same
+            # pixels and comment, deflated on all cores instead of one
+            fastpng.save_rgb(path, rgb, comment)
+        else:
+            Image.fromarray(rgb).save(path)
     spent = time.perf_counter() - start_time
     steps_time = sum(transfer.step_times)
     if steps_time > 0:

@@ -82,6 +82,10 @@ struct ContentWindow {
     int ch, cw;             // full content map size
     int oy, ox;             // window origin in the rolled map
     int sy, sx;             // roll shifts (rows, cols)
+    // Replayed launch graphs (engine.cpp: TileGraph) cannot carry the iteration's shift as a
+    // kernel argument: when non-null, {oy - sy, ox - sx} is read from these two device ints
+    // (written on the stream just before the graph is launched) and oy/ox/sy/sx are ignored.
+    const int *dyn = nullptr;
 };
 
 // Loss-gradient terms added by the backward-data epilogue to the gradient it produces (the
@@ -219,11 +223,15 @@ int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &pla
 // sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
 // content map.
 #ifdef __HIPCC__
+// Window origin in the un-rolled content map, before wrapping: (oy - sy, ox - sx), or the two
+// device ints of a replayed launch graph (ContentWindow::dyn; uniform scalar loads).
+__device__ __forceinline__ int content_origin_y(const ContentWindow &w) { return w.dyn ? w.dyn[0] : w.oy - w.sy; }
+__device__ __forceinline__ int content_origin_x(const ContentWindow &w) { return w.dyn ? w.dyn[1] : w.ox - w.sx; }
 // Rolled content value at tile-feature position (c, y, x):
 // roll2(Fc, (sx, sy))[c][oy + y][ox + x] = Fc[c][(oy + y - sy) mod ch][(ox + x - sx) mod cw]
 __device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, int y, int x) {
-    int yy = (w.oy + y - w.sy) % w.ch;
-    int xx = (w.ox + x - w.sx) % w.cw;
+    int yy = (content_origin_y(w) + y) % w.ch;
+    int xx = (content_origin_x(w) + x) % w.cw;
     if (yy < 0) yy += w.ch;
     if (xx < 0) xx += w.cw;
     return ((size_t)c * w.ch + yy) * w.cw + xx;
@@ -238,6 +246,7 @@ int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef, bool accumulate);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
+int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
 
 // image_ops.hip

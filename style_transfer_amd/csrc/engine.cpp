@@ -8,6 +8,7 @@
 // queues and POSIX shared memory.
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,10 @@ void set_error(const char *fmt, ...) {
     g_error = buf;
 }
 
+// Bumped whenever a DevBuf is (re)allocated or released: a recorded launch graph (TileGraph) holds
+// raw device pointers and is only replayed while the epoch it was captured under still stands.
+static std::atomic<unsigned long> g_alloc_epoch{0};
+
 // Growable device buffer.  Growth frees and reallocates (hipFree synchronises the device, so
 // kernels still reading the old allocation have finished); it happens only when a larger tile
 // than ever before arrives.
@@ -41,6 +46,7 @@ struct DevBuf {
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return STX_OK;
+        ++g_alloc_epoch;
         if (ptr) STX_HIP(hipFree(ptr));
         ptr = nullptr;
         bytes = 0;
@@ -55,7 +61,10 @@ struct DevBuf {
         return STX_OK;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) {
+            ++g_alloc_epoch;
+            (void)hipFree(ptr);
+        }
         ptr = nullptr;
         bytes = 0;
     }
@@ -107,6 +116,63 @@ struct PendingLoss {
     double *out;
     std::vector<LossTerm> terms;       // sum coef * scalar
     std::vector<LossTerm> dterms;      // sum coef * double scalar (image ops)
+    const float *host = nullptr;       // mirror the float terms index (null: the engine's own)
+};
+
+// What the engines of one GPU have in common: the network's weights, the banks packed for the
+// kernels and the current targets.  A farm runs several engines (HIP streams + activation
+// buffers) per GPU; each holding its own copy cost 4 x (80 MB of weights + ~200 MB of packed
+// banks + the per-scale content maps: 537 MB at 4096^2) per GPU and as many uploads over xGMI.
+struct SharedState {
+    std::map<int, ConvParams> conv;    // layer index -> params
+    std::vector<ContentTarget> contents;
+    std::vector<StyleTarget> styles;
+    int n_contents = 0, n_styles = 0;
+    std::vector<stx_engine *> members;
+    std::mutex mutex;                  // packs and target swaps (members may be driven by different threads)
+    size_t target_uploads = 0;         // stx_set_contents_and_styles calls that copied data
+    double target_bytes = 0;           // bytes those calls copied (cumulative)
+};
+
+// One content-map window of a recorded tile evaluation: what is needed to recompute its origin
+// for the call at hand (start // scale - roll // scale) and to re-validate it.
+struct DynWindow {
+    int scale, fh, fw, ch, cw;
+    std::string blob;
+};
+
+// A recorded stx_sc_grad_tile: everything between the tile landing in the input blob and the
+// gradient standing in its diff, as one hipGraph.  The launch-bound small scales of a pyramid
+// spend ~17 us of host time per kernel on ~65 kernels per tile (1.19 ms for a 256^2 tile whose
+// kernels need less than half of that); a replay is one call.  Per-call state that the recorded
+// kernels cannot carry as arguments lives in device memory owned by the graph: the content
+// windows' origins (`dyn`, rewritten before every launch) and the loss scalars.
+struct TileGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long epoch = 0;
+    int eager_calls = 0;               // evaluations of this key run eagerly so far (same epoch)
+    bool disabled = false;             // capture failed once: stay eager
+    bool in_flight = false;            // launched since the last stx_sync (its scalars are unread)
+    float *scalars = nullptr;          // loss scalars of this recording (raw allocations: they must not
+    int *dyn = nullptr;                // move the allocation epoch) and the content-window origins
+    float *scalars_host = nullptr;
+    size_t scalars_cap = 0, scalars_used = 0;
+    std::vector<DynWindow> windows;
+    std::vector<LossTerm> terms;
+    double flop_algorithmic = 0, flop_issued = 0;
+    void destroy_graph() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr;
+        graph = nullptr;
+    }
+    ~TileGraph() {
+        destroy_graph();
+        if (scalars) (void)hipFree(scalars);
+        if (dyn) (void)hipFree(dyn);
+        if (scalars_host) (void)hipHostFree(scalars_host);
+    }
 };
 
 }  // namespace stx
@@ -126,16 +192,24 @@ struct stx_engine {
     std::vector<Layer> layers;
     std::vector<Blob> blobs;
     std::map<std::string, int> blob_index, layer_index;
-    std::map<int, ConvParams> conv;   // layer index -> params
-    std::vector<ContentTarget> contents;
-    std::vector<StyleTarget> styles;
-    int n_contents = 0, n_styles = 0;
+    std::shared_ptr<SharedState> sh;   // weights, packed banks, targets (shared per GPU)
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
     DevBuf gram_partials, gram, dsym, symm_partials, upload;
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
     size_t scalars_cap = 0, scalars_used = 0;
+    // the arena alloc_scalars serves from: the engine's own, or a TileGraph's while it is recorded
+    float *arena_dev = nullptr;
+    size_t arena_cap = 0, *arena_used = nullptr;
+    // recorded tile evaluations (STX_GRAPH=0 turns them off), keyed by everything a recording bakes in
+    bool graphs_on = true;
+    int graph_min_eager = 2;
+    TileGraph *recording = nullptr;
+    std::map<std::string, std::unique_ptr<TileGraph>> graphs;
+    size_t n_captures = 0, n_replays = 0, n_eager = 0;
+    std::vector<hipEvent_t> fence_events;     // stx_engine_wait: ring of events recorded on this stream
+    size_t fence_next = 0;
     DevBuf dscalars;                   // device doubles (image-op reductions)
     double *dscalars_host = nullptr;
     size_t dscalars_cap = 64, dscalars_used = 0;
@@ -206,13 +280,19 @@ double conv_flops(int K, int M, int H, int W, int ks) {
 
 
 int alloc_scalars(stx_engine *e, size_t n, size_t *index) {
-    if (e->scalars_used + n > e->scalars_cap) {
-        set_error("scalar arena exhausted (%zu + %zu > %zu)", e->scalars_used, n, e->scalars_cap);
+    if (*e->arena_used + n > e->arena_cap) {
+        set_error("scalar arena exhausted (%zu + %zu > %zu)", *e->arena_used, n, e->arena_cap);
         return STX_ERR_NOMEM;
     }
-    *index = e->scalars_used;
-    e->scalars_used += n;
+    *index = *e->arena_used;
+    *e->arena_used += n;
     return STX_OK;
+}
+
+void use_own_arena(stx_engine *e) {
+    e->arena_dev = e->scalars.f();
+    e->arena_cap = e->scalars_cap;
+    e->arena_used = &e->scalars_used;
 }
 
 int alloc_dscalars(stx_engine *e, size_t n, size_t *index) {
@@ -281,7 +361,8 @@ void mark_ancestors(const stx_engine *e, int blob, std::vector<char> &needed) {
 }
 
 int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const float **out) {
-    ConvParams &cp = e->conv[layer];
+    std::lock_guard<std::mutex> lock(e->sh->mutex);
+    ConvParams &cp = e->sh->conv[layer];
     if (!cp.set) {
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
@@ -289,6 +370,10 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
     const int key = dir * 1024 + (cfg.id >= 200 ? 200 : cfg.id);   // both 2-D geometries share a bank
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
+        if (e->recording) {
+            set_error("a filter bank would have to be packed while a launch graph is recorded");
+            return STX_ERR_STATE;
+        }
         const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
         std::unique_ptr<DevBuf> buf(new DevBuf);
         if (cfg.id >= 100) {   // Winograd-transformed bank
@@ -299,6 +384,8 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
             STX_TRY(conv_pack_weights(e->stream, cp.w.f(), cp.cout, cp.cin, cp.ks, dir, cfg,
                                       buf->f()));
         }
+        // the other engines of this GPU will read the bank from their own streams
+        if (e->sh->members.size() > 1) STX_HIP(hipStreamSynchronize(e->stream));
         it = cp.packed.emplace(key, std::move(buf)).first;
     }
     *out = it->second->f();
@@ -436,7 +523,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     const Layer &L = e->layers[li];
     const Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
-    const ConvParams &cp = e->conv[li];
+    const ConvParams &cp = e->sh->conv[li];
     ConvProblem p{};
     p.x = b.data.f();
     p.y = t.data.f();
@@ -479,7 +566,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     const Layer &L = e->layers[li];
     Blob &b = e->blobs[L.bottom_blob];
     const Blob &t = e->blobs[L.top_blob];
-    const ConvParams &cp = e->conv[li];
+    const ConvParams &cp = e->sh->conv[li];
     ConvProblem p{};
     p.x = t.diff.f();
     p.y = b.diff.f();
@@ -493,12 +580,14 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     if (cp.ks == 3 && cp.cin <= 4) {
         // backward into a <= 4-channel blob (the image): dedicated 4x4x1-MFMA kernel
         if (fused) *fused = false;
-        ConvParams &cpm = e->conv[li];
+        std::lock_guard<std::mutex> lock(e->sh->mutex);
+        ConvParams &cpm = e->sh->conv[li];
         auto it = cpm.packed.find(1 * 1024 + 999);
         if (it == cpm.packed.end()) {
             std::unique_ptr<DevBuf> buf(new DevBuf);
             STX_TRY(buf->ensure(conv_small_packed_floats(cp.cout) * sizeof(float)));
             STX_TRY(conv_small_pack(e->stream, cp.w.f(), cp.cout, cp.cin, 1, buf->f()));
+            if (e->sh->members.size() > 1) STX_HIP(hipStreamSynchronize(e->stream));
             it = cpm.packed.emplace(1 * 1024 + 999, std::move(buf)).first;
         }
         ProfScope scope(e, "bwd " + L.name, conv_flops(cp.cout, cp.cin, b.h, b.w, cp.ks));
@@ -589,19 +678,28 @@ int end_timing(stx_engine *e) {
 int publish_pending(stx_engine *e) {
     for (const PendingLoss &pl : e->pending) {
         double v = 0.0;
-        for (const LossTerm &t : pl.terms) v += t.coef * (double)e->scalars_host[t.scalar_index];
+        const float *host = pl.host ? pl.host : e->scalars_host;
+        for (const LossTerm &t : pl.terms) v += t.coef * (double)host[t.scalar_index];
         for (const LossTerm &t : pl.dterms) v += t.coef * e->dscalars_host[t.scalar_index];
         if (pl.out) *pl.out = v;
     }
     e->pending.clear();
     e->scalars_used = 0;
     e->dscalars_used = 0;
+    for (auto &kv : e->graphs) kv.second->in_flight = false;
     return STX_OK;
 }
 
 int do_sync(stx_engine *e) {
     STX_HIP(hipStreamSynchronize(e->stream));
     return publish_pending(e);
+}
+
+// Waits for the streams of every engine that shares e's state (weights or targets are about to be
+// replaced under them).  Their pending results stay pending.
+int quiesce_members(stx_engine *e) {
+    for (stx_engine *m : e->sh->members) STX_HIP(hipStreamSynchronize(m->stream));
+    return STX_OK;
 }
 
 }  // namespace
@@ -635,7 +733,11 @@ int stx_device_name(int device, char *buf, size_t buf_len) {
     return STX_OK;
 }
 
-int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, stx_engine **out) {
+}  // extern "C"
+
+// `share`: the state of an engine on the same GPU to join (weights, packed banks, targets), or null.
+static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
+                        std::shared_ptr<SharedState> share, stx_engine **out) {
     if (!layers || n_layers < 2 || !out) {
         set_error("stx_engine_create: bad arguments");
         return STX_ERR_ARG;
@@ -646,6 +748,8 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     }
     std::unique_ptr<stx_engine> e(new stx_engine);
     e->device = device;
+    const bool joined = share != nullptr;
+    e->sh = joined ? share : std::make_shared<SharedState>();
     hipError_t err = hipSetDevice(device);
     if (err != hipSuccess) {
         set_error("hipSetDevice(%d): %s", device, hipGetErrorString(err));
@@ -703,10 +807,12 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
                     return STX_ERR_UNSUPPORTED;
                 }
                 L.top_blob = add_blob(L.top, L.num_output, i);
-                ConvParams &cp = e->conv[i];
-                cp.cin = e->blobs[L.bottom_blob].channels;
-                cp.cout = L.num_output;
-                cp.ks = L.ksize;
+                if (!joined) {
+                    ConvParams &cp = e->sh->conv[i];
+                    cp.cin = e->blobs[L.bottom_blob].channels;
+                    cp.cout = L.num_output;
+                    cp.ks = L.ksize;
+                }
             } else if (L.type == STX_LAYER_POOL) {
                 if (L.ksize != 2 || L.stride != 2 ||
                     (L.pool_mode != STX_POOL_MAX && L.pool_mode != STX_POOL_AVE)) {
@@ -768,6 +874,8 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
     if (const char *env = getenv("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
     if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
+    if (const char *env = getenv("STX_GRAPH")) e->graphs_on = atoi(env) != 0;
+    if (const char *env = getenv("STX_GRAPH_MIN_EAGER")) e->graph_min_eager = std::max(1, atoi(env));
     e->scalars_cap = kScalarFloats;
     STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
@@ -776,8 +884,41 @@ int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, st
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->dscalars_host),
                           e->dscalars_cap * sizeof(double), hipHostMallocDefault));
     STX_TRY(e->red_scratch.ensure(4 * 1024 * sizeof(float)));
+    use_own_arena(e.get());
+    {
+        std::lock_guard<std::mutex> lock(e->sh->mutex);
+        e->sh->members.push_back(e.get());
+    }
     *out = e.release();
     return STX_OK;
+}
+
+extern "C" {
+
+int stx_engine_create(int device, const stx_layer_desc *layers, int n_layers, stx_engine **out) {
+    return build_engine(device, layers, n_layers, nullptr, out);
+}
+
+int stx_engine_create_shared(stx_engine *primary, stx_engine **out) {
+    if (!primary || !out) {
+        set_error("stx_engine_create_shared: bad arguments");
+        return STX_ERR_ARG;
+    }
+    std::vector<stx_layer_desc> descs(primary->layers.size());
+    for (size_t i = 0; i < descs.size(); ++i) {
+        const Layer &L = primary->layers[i];
+        stx_layer_desc &d = descs[i];
+        d.name = L.name.c_str();
+        d.type = L.type;
+        d.bottom = L.bottom.empty() ? nullptr : L.bottom.c_str();
+        d.top = L.top.c_str();
+        d.num_output = i == 0 ? primary->blobs[L.top_blob].channels : L.num_output;
+        d.kernel_size = L.ksize;
+        d.pad = L.pad;
+        d.stride = L.stride;
+        d.pool_mode = L.pool_mode;
+    }
+    return build_engine(primary->device, descs.data(), (int)descs.size(), primary->sh, out);
 }
 
 void stx_engine_destroy(stx_engine *e) {
@@ -794,13 +935,24 @@ void stx_engine_destroy(stx_engine *e) {
         b.diff.release();
         b.codes.release();
     }
-    for (auto &kv : e->conv) {
-        kv.second.w.release();
-        kv.second.b.release();
-        for (auto &p : kv.second.packed) p.second->release();
+    e->graphs.clear();
+    for (hipEvent_t ev : e->fence_events) (void)hipEventDestroy(ev);
+    bool last;
+    {
+        std::lock_guard<std::mutex> lock(e->sh->mutex);
+        auto &m = e->sh->members;
+        m.erase(std::remove(m.begin(), m.end(), e), m.end());
+        last = m.empty();
     }
-    for (auto &c : e->contents) c.feat->release();
-    for (auto &s : e->styles) s.gram->release();
+    if (last) {     // the shared state goes with its last engine
+        for (auto &kv : e->sh->conv) {
+            kv.second.w.release();
+            kv.second.b.release();
+            for (auto &p : kv.second.packed) p.second->release();
+        }
+        for (auto &c : e->sh->contents) c.feat->release();
+        for (auto &s : e->sh->styles) s.gram->release();
+    }
     DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
                       &e->upload, &e->scalars, &e->dscalars, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
@@ -828,7 +980,10 @@ int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *wei
         set_error("stx_set_conv_weights: '%s' is not a convolution layer", conv_layer);
         return STX_ERR_ARG;
     }
-    ConvParams &cp = e->conv[it->second];
+    std::lock_guard<std::mutex> lock(e->sh->mutex);
+    const bool shared = e->sh->members.size() > 1;
+    if (shared) STX_TRY(quiesce_members(e));
+    ConvParams &cp = e->sh->conv[it->second];
     const size_t nw = (size_t)cp.cout * cp.cin * cp.ks * cp.ks;
     STX_TRY(cp.w.ensure(nw * sizeof(float)));
     STX_TRY(cp.b.ensure((size_t)cp.cout * sizeof(float)));
@@ -837,8 +992,9 @@ int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *wei
         STX_TRY(copy_in(e, cp.b.ptr, bias, mem, (size_t)cp.cout * sizeof(float)));
     else
         STX_HIP(hipMemsetAsync(cp.b.ptr, 0, (size_t)cp.cout * sizeof(float), e->stream));
-    // host buffers may be reused by the caller right away
-    if (mem == STX_HOST) STX_HIP(hipStreamSynchronize(e->stream));
+    // host buffers may be reused by the caller right away; engines sharing the bank read it from
+    // their own streams
+    if (mem == STX_HOST || shared) STX_HIP(hipStreamSynchronize(e->stream));
     for (auto &p : cp.packed) p.second->release();
     cp.packed.clear();
     cp.set = true;
@@ -860,6 +1016,51 @@ int stx_engine_device(stx_engine *e, int *device) {
 int stx_engine_stream(stx_engine *e, void **hip_stream) {
     if (!e || !hip_stream) return STX_ERR_ARG;
     *hip_stream = e->stream;
+    return STX_OK;
+}
+
+int stx_engine_wait(stx_engine *e, stx_engine *other) {
+    if (!e || !other) return STX_ERR_ARG;
+    if (e == other) return STX_OK;
+    constexpr size_t kRing = 16;    // a wait reads the event's state when it is queued: re-recording later is safe
+    STX_TRY(other->set_device());
+    if (other->fence_events.size() < kRing) {
+        hipEvent_t ev;
+        STX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        other->fence_events.push_back(ev);
+        other->fence_next = other->fence_events.size() - 1;
+    }
+    hipEvent_t ev = other->fence_events[other->fence_next];
+    other->fence_next = (other->fence_next + 1) % kRing;
+    STX_HIP(hipEventRecord(ev, other->stream));
+    STX_TRY(e->set_device());
+    STX_HIP(hipStreamWaitEvent(e->stream, ev, 0));
+    return STX_OK;
+}
+
+int stx_engine_query(stx_engine *e, int what, double *value) {
+    if (!e || !value) return STX_ERR_ARG;
+    std::lock_guard<std::mutex> lock(e->sh->mutex);
+    switch (what) {
+        case STX_Q_SHARED_ENGINES: *value = (double)e->sh->members.size(); break;
+        case STX_Q_TARGET_UPLOADS: *value = (double)e->sh->target_uploads; break;
+        case STX_Q_TARGET_BYTES: *value = e->sh->target_bytes; break;
+        case STX_Q_WEIGHT_BYTES: {
+            double b = 0;
+            for (auto &kv : e->sh->conv) {
+                b += (double)kv.second.w.bytes + (double)kv.second.b.bytes;
+                for (auto &p : kv.second.packed) b += (double)p.second->bytes;
+            }
+            *value = b;
+            break;
+        }
+        case STX_Q_GRAPH_CAPTURES: *value = (double)e->n_captures; break;
+        case STX_Q_GRAPH_REPLAYS: *value = (double)e->n_replays; break;
+        case STX_Q_EAGER_TILES: *value = (double)e->n_eager; break;
+        default:
+            set_error("stx_engine_query: unknown item %d", what);
+            return STX_ERR_ARG;
+    }
     return STX_OK;
 }
 
@@ -904,13 +1105,16 @@ int stx_set_contents_and_styles(stx_engine *e, const stx_content_target *content
                                 const stx_style_target *styles, int n_styles) {
     if (!e || (n_contents && !contents) || (n_styles && !styles)) return STX_ERR_ARG;
     STX_TRY(e->set_device());
-    // the previous targets may still be in use by queued kernels
-    STX_HIP(hipStreamSynchronize(e->stream));
-    for (auto &c : e->contents) c.feat->release();
-    for (auto &s : e->styles) s.gram->release();
-    e->contents.clear();
-    e->styles.clear();
-    e->n_contents = e->n_styles = 0;
+    std::lock_guard<std::mutex> lock(e->sh->mutex);
+    const bool shared = e->sh->members.size() > 1;
+    // the previous targets may still be in use by queued kernels (of any engine that shares them)
+    STX_TRY(quiesce_members(e));
+    double copied = 0;
+    for (auto &c : e->sh->contents) c.feat->release();
+    for (auto &s : e->sh->styles) s.gram->release();
+    e->sh->contents.clear();
+    e->sh->styles.clear();
+    e->sh->n_contents = e->sh->n_styles = 0;
     bool host_src = false;
     for (int i = 0; i < n_contents; ++i) {
         const stx_content_target &c = contents[i];
@@ -930,9 +1134,10 @@ int stx_set_contents_and_styles(stx_engine *e, const stx_content_target *content
         const size_t bytes = (size_t)t.C * t.h * t.w * sizeof(float);
         STX_TRY(t.feat->ensure(bytes));
         STX_TRY(copy_in(e, t.feat->ptr, c.features, c.mem, bytes));
+        copied += (double)bytes;
         host_src |= c.mem == STX_HOST;
-        e->n_contents = std::max(e->n_contents, t.index + 1);
-        e->contents.push_back(std::move(t));
+        e->sh->n_contents = std::max(e->sh->n_contents, t.index + 1);
+        e->sh->contents.push_back(std::move(t));
     }
     for (int i = 0; i < n_styles; ++i) {
         const stx_style_target &s = styles[i];
@@ -949,11 +1154,15 @@ int stx_set_contents_and_styles(stx_engine *e, const stx_content_target *content
         const size_t bytes = (size_t)t.C * t.C * sizeof(float);
         STX_TRY(t.gram->ensure(bytes));
         STX_TRY(copy_in(e, t.gram->ptr, s.gram, s.mem, bytes));
+        copied += (double)bytes;
         host_src |= s.mem == STX_HOST;
-        e->n_styles = std::max(e->n_styles, t.index + 1);
-        e->styles.push_back(std::move(t));
+        e->sh->n_styles = std::max(e->sh->n_styles, t.index + 1);
+        e->sh->styles.push_back(std::move(t));
     }
-    if (host_src) STX_HIP(hipStreamSynchronize(e->stream));
+    // (the sharing engines use the new targets from their own streams)
+    if (host_src || shared) STX_HIP(hipStreamSynchronize(e->stream));
+    e->sh->target_uploads += 1;
+    e->sh->target_bytes += copied;
     return STX_OK;
 }
 
@@ -989,32 +1198,39 @@ int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int 
     return STX_OK;
 }
 
-int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
-                     const int roll_xy[2], const int start_yx[2], const stx_tap *taps, int n_taps,
-                     double *loss_out, float *grad_out, int grad_mem, int sync_now) {
-    if (!e || !img || th <= 0 || tw <= 0 || !taps || n_taps <= 0 || !grad_out || !start_yx) {
-        set_error("stx_sc_grad_tile: bad arguments");
-        return STX_ERR_ARG;
-    }
-    STX_TRY(e->set_device());
-    const int rx = roll_xy ? roll_xy[0] : 0, ry = roll_xy ? roll_xy[1] : 0;
-    // the scalar arena holds the reductions of every call queued since the last stx_sync; drain
-    // it (publishing the pending losses) before it could overflow
-    {
-        const size_t per_call = (size_t)n_taps * 2100 * (size_t)std::max(1, e->n_contents + e->n_styles);
-        if (e->scalars_used + per_call > e->scalars_cap) STX_TRY(do_sync(e));
-        if (per_call > e->scalars_cap) {
-            set_error("stx_sc_grad_tile: %d taps need more scalar space than the arena holds", n_taps);
-            return STX_ERR_NOMEM;
-        }
-    }
+}  // extern "C"
 
+namespace {
+
+constexpr size_t kMaxDynWindows = 32;
+
+struct Tap {
+    int blob;
+    const stx_tap *t;
+};
+
+// One stx_sc_grad_tile call.
+struct TileCall {
+    const float *img;
+    int img_mem, th, tw, rx, ry, start[2];
+    const stx_tap *taps;
+    int n_taps;
+    float *grad_out;
+    int grad_mem;
+};
+
+struct TilePlan {
+    std::vector<Tap> order;         // taps, deepest first
+    std::vector<char> needed;       // blobs on the path
+    std::vector<int> tap_of;        // blob -> index into order, or -1
+};
+
+// Validates the taps against the graph and the targets, orders them and shapes the blobs.
+int sc_grad_prepare(stx_engine *e, const TileCall &c, TilePlan &plan) {
     // ---- taps in deep -> shallow order (style_transfer.py:231-233)
-    struct Tap {
-        int blob;
-        const stx_tap *t;
-    };
-    std::vector<Tap> order;
+    std::vector<Tap> &order = plan.order;
+    const stx_tap *taps = c.taps;
+    const int n_taps = c.n_taps;
     for (int i = 0; i < n_taps; ++i) {
         const int blob = e->find_blob(taps[i].layer);
         if (blob <= 0) {
@@ -1035,9 +1251,11 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         return STX_ERR_ARG;
     }
     std::sort(order.begin(), order.end(), [](const Tap &a, const Tap &b) { return a.blob > b.blob; });
-    std::vector<char> needed(e->blobs.size(), 0);
+    std::vector<char> &needed = plan.needed;
+    needed.assign(e->blobs.size(), 0);
     mark_ancestors(e, order[0].blob, needed);
-    std::vector<int> tap_of(e->blobs.size(), -1);
+    std::vector<int> &tap_of = plan.tap_of;
+    tap_of.assign(e->blobs.size(), -1);
     for (size_t i = 0; i < order.size(); ++i) {
         if (!needed[order[i].blob]) {
             set_error("stx_sc_grad_tile: tapped layers must lie on one path through the network "
@@ -1048,23 +1266,28 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         tap_of[order[i].blob] = (int)i;
     }
     for (const Tap &tp : order) {
-        if (tp.t->is_content && e->n_contents == 0) {
+        if (tp.t->is_content && e->sh->n_contents == 0) {
             set_error("stx_sc_grad_tile: no content targets set");
             return STX_ERR_STATE;
         }
-        if (tp.t->is_style && e->n_styles == 0) {
+        if (tp.t->is_style && e->sh->n_styles == 0) {
             set_error("stx_sc_grad_tile: no style targets set");
             return STX_ERR_STATE;
         }
     }
 
-    STX_TRY(shape_blobs(e, th, tw, needed, true));
-    const int data_blob = e->layers[0].top_blob;
-    Blob &in = e->blobs[data_blob];
-    STX_TRY(copy_in(e, in.data.ptr, img, img_mem, in.count() * sizeof(float)));
+    return shape_blobs(e, c.th, c.tw, needed, true);
+}
 
-    PendingLoss pl;
-    pl.out = loss_out;
+// Enqueues the evaluation proper: forward pass with the loss terms of the tapped blobs, backward
+// walk, the mirror copy of the loss scalars.  The tile is already in the input blob; the gradient
+// is left in its diff.  `g` non-null: the stream is being recorded into g (no timing events; the
+// content windows take their origin from g's device memory).
+int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingLoss &pl, TileGraph *g) {
+    const std::vector<Tap> &order = plan.order;
+    const std::vector<char> &needed = plan.needed;
+    const std::vector<int> &tap_of = plan.tap_of;
+    const int data_blob = e->layers[0].top_blob;
 
     // ---- loss terms of the tapped blobs.  They depend only on the forward activations, so they
     // are all queued right after the forward pass (optionally on a side stream, see
@@ -1077,6 +1300,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         ContentWindow win;
     };
     std::vector<std::vector<Term>> terms(order.size());
+    const bool two_streams = e->side != e->stream;
     while (e->ev_tap.size() < order.size()) {
         hipEvent_t ev;
         STX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1094,7 +1318,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         const double lw = tp.t->layer_weight;
         if (tp.t->is_content) {
             bool any = false;
-            for (const ContentTarget &ct : e->contents) {
+            for (const ContentTarget &ct : e->sh->contents) {
                 if (ct.blob != tp.blob) continue;
                 any = true;
                 ContentWindow win;
@@ -1104,18 +1328,26 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 win.ch = ct.h;
                 win.cw = ct.w;
                 // start_ = start // scale (style_transfer.py:572); roll // scale per layer (:647-655)
-                win.oy = (int)std::floor((double)start_yx[0] / b.scale);
-                win.ox = (int)std::floor((double)start_yx[1] / b.scale);
-                win.sx = (int)std::floor((double)rx / b.scale);
-                win.sy = (int)std::floor((double)ry / b.scale);
+                win.oy = (int)std::floor((double)c.start[0] / b.scale);
+                win.ox = (int)std::floor((double)c.start[1] / b.scale);
+                win.sx = (int)std::floor((double)c.rx / b.scale);
+                win.sy = (int)std::floor((double)c.ry / b.scale);
                 if (win.oy + win.fh > win.ch || win.ox + win.fw > win.cw) {
                     set_error("content window [%d+%d, %d+%d] exceeds the %dx%d map of layer %s",
                               win.oy, win.fh, win.ox, win.fw, win.ch, win.cw, b.name.c_str());
                     return STX_ERR_ARG;
                 }
+                if (g) {    // recorded: the origin is read from device memory at run time
+                    win.dyn = g->dyn + 2 * g->windows.size();
+                    g->windows.push_back(DynWindow{b.scale, b.h, b.w, ct.h, ct.w, b.name});
+                    if (g->windows.size() > kMaxDynWindows) {
+                        set_error("too many content windows for one launch graph");
+                        return STX_ERR_UNSUPPORTED;
+                    }
+                }
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-                float *sums = e->scalars.f() + si;
+                float *sums = e->arena_dev + si;
                 {
                     ProfScope scope(e, "content " + b.name, 0.0, e->side);
                     STX_TRY(content_sums_launch(e->side, b.data.f(), ct.feat->f(), win, sums));
@@ -1131,14 +1363,14 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         }
         if (tp.t->is_style) {
             int n_here = 0;
-            for (const StyleTarget &st : e->styles) n_here += st.blob == tp.blob;
+            for (const StyleTarget &st : e->sh->styles) n_here += st.blob == tp.blob;
             if (!n_here) {
                 set_error("no style target for layer %s", b.name.c_str());
                 return STX_ERR_STATE;
             }
             STX_TRY(e->sgrad_tap[k]->ensure((size_t)n_here * b.count() * sizeof(float)));
             int slot = 0;
-            for (const StyleTarget &st : e->styles) {
+            for (const StyleTarget &st : e->sh->styles) {
                 if (st.blob != tp.blob) continue;
                 const int C = b.channels, HW = b.h * b.w;
                 if (C % 4 != 0) {
@@ -1153,7 +1385,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                 float *sgrad = e->sgrad_tap[k]->f() + (size_t)slot++ * b.count();
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
-                float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
+                float *sc = e->arena_dev + si;   // [0] = sum tril(D)^2, [1] = sum |S|
                 {
                     ProfScope scope(e, "gram " + b.name, 2.0 * C * C * (double)HW, e->side);
                     STX_TRY(gram_partials_launch(e->side, b.data.f(), plan, e->gram_partials.f()));
@@ -1180,9 +1412,9 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                     STX_TRY(conv_launch(e->side, cfg, p, false));
                     STX_TRY(sum_partials_launch(e->side, e->symm_partials.f(), n_wg, sc + 1));
                 }
-                pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->n_styles});
+                pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
                 terms[k].push_back(Term{true, sgrad, sc + 1,
-                                        (float)(lw * tp.t->style_weight / e->n_styles), ContentWindow{}});
+                                        (float)(lw * tp.t->style_weight / e->sh->n_styles), ContentWindow{}});
             }
         }
         if (tp.t->is_dd) {
@@ -1194,7 +1426,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             win.fw = win.cw = b.w;
             size_t si;
             STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-            float *sums = e->scalars.f() + si;
+            float *sums = e->arena_dev + si;
             {
                 ProfScope scope(e, "dream " + b.name, 0.0, e->side);
                 STX_TRY(content_sums_launch(e->side, b.data.f(), nullptr, win, sums));
@@ -1202,7 +1434,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             pl.terms.push_back(LossTerm{si, -lw * tp.t->dd_weight * 0.5});
             terms[k].push_back(Term{false, nullptr, sums, (float)(-lw * tp.t->dd_weight), win});
         }
-        STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
+        if (two_streams) STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
         return STX_OK;
     };
     // (STX_TERMS_LATE=1: all loss terms after the forward pass, for A/B measurements)
@@ -1211,7 +1443,8 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         const int k = tap_of[blob];
         return k >= 0 ? launch_terms((size_t)k) : STX_OK;
     };
-    STX_TRY(begin_timing(e));
+    if (!g) STX_TRY(begin_timing(e));
+    e->flop_algorithmic = e->flop_issued = 0;
     STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr));
     if (!interleave) {
         STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
@@ -1248,7 +1481,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
     int cur = order[0].blob;
     {
-        STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[0], 0));
+        if (two_streams) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[0], 0));
         bool written = false;
         STX_TRY(inject(0, written));
         if (!written)
@@ -1261,7 +1494,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
         Blob &bot = e->blobs[L.bottom_blob];
         const Blob &top = e->blobs[cur];
         const int k = tap_of[L.bottom_blob];
-        if (k >= 0) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[k], 0));
+        if (k >= 0 && two_streams) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[k], 0));
         bool fused = false;
         if (L.type == STX_LAYER_CONV) {
             ConvInject inj{};
@@ -1298,12 +1531,219 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
             STX_TRY(inject((size_t)k, written));
         }
     }
-    STX_TRY(end_timing(e));
-    STX_TRY(copy_out(e, grad_out, grad_mem, in.diff.ptr, in.count() * sizeof(float)));
+    if (!g) STX_TRY(end_timing(e));
     // mirror the scalars used so far (small) for the loss
-    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
-                           hipMemcpyDeviceToHost, e->stream));
+    STX_HIP(hipMemcpyAsync(g ? g->scalars_host : e->scalars_host, e->arena_dev,
+                           *e->arena_used * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    return STX_OK;
+}
+
+// Everything a recording bakes in: tile shape, taps (blobs, flags, weights) and, through the
+// allocation epoch checked by the caller, every device pointer.  `instance` tells apart several
+// uses of one key between two stx_sync calls (each owns its loss scalars).
+std::string graph_key(stx_engine *e, const TileCall &c, int instance) {
+    std::string key;
+    auto put = [&](const void *p, size_t n) { key.append(static_cast<const char *>(p), n); };
+    const int head[4] = {c.th, c.tw, c.n_taps, instance};
+    put(head, sizeof head);
+    for (int i = 0; i < c.n_taps; ++i) {
+        const stx_tap &t = c.taps[i];
+        const int blob = e->find_blob(t.layer);
+        const int flags[4] = {blob, t.is_content, t.is_style, t.is_dd};
+        const double w[4] = {t.layer_weight, t.content_weight, t.style_weight, t.dd_weight};
+        put(flags, sizeof flags);
+        put(w, sizeof w);
+    }
+    return key;
+}
+
+int graph_record(stx_engine *e, TileGraph *g, const TileCall &c) {
+    TilePlan plan;
+    STX_TRY(sc_grad_prepare(e, c, plan));
+    const size_t need = (size_t)c.n_taps * 2100 *
+                        (size_t)std::max(1, e->sh->n_contents + e->sh->n_styles);
+    if (g->scalars && need > g->scalars_cap) {      // more targets than when this key was first recorded
+        STX_HIP(hipStreamSynchronize(e->stream));
+        (void)hipFree(g->scalars);
+        (void)hipFree(g->dyn);
+        (void)hipHostFree(g->scalars_host);
+        g->scalars = nullptr;
+    }
+    if (!g->scalars) {
+        g->scalars_cap = need;
+        STX_HIP(hipMalloc(reinterpret_cast<void **>(&g->scalars), g->scalars_cap * sizeof(float)));
+        STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->scalars_host),
+                              g->scalars_cap * sizeof(float), hipHostMallocDefault));
+        STX_HIP(hipMalloc(reinterpret_cast<void **>(&g->dyn), 2 * kMaxDynWindows * sizeof(int)));
+    }
+    g->destroy_graph();
+    g->windows.clear();
+    g->scalars_used = 0;
+    const unsigned long epoch = g_alloc_epoch.load();
+    e->arena_dev = g->scalars;
+    e->arena_cap = g->scalars_cap;
+    e->arena_used = &g->scalars_used;
+    e->recording = g;
+    PendingLoss pl;
+    int rc = STX_OK;
+    hipError_t err = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
+    if (err == hipSuccess) {
+        rc = sc_grad_run(e, c, plan, pl, g);
+        err = hipStreamEndCapture(e->stream, &g->graph);
+    }
+    e->recording = nullptr;
+    use_own_arena(e);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("stream capture failed: %s", hipGetErrorString(err));
+        rc = STX_ERR_HIP;
+    }
+    if (rc == STX_OK && g_alloc_epoch.load() != epoch) {
+        set_error("device memory was reallocated while a launch graph was recorded");
+        rc = STX_ERR_STATE;
+    }
+    if (rc == STX_OK) {
+        err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
+            rc = STX_ERR_HIP;
+        }
+    }
+    if (rc != STX_OK) {
+        g->destroy_graph();
+        return rc;
+    }
+    g->epoch = epoch;
+    g->terms = pl.terms;
+    g->flop_algorithmic = e->flop_algorithmic;
+    g->flop_issued = e->flop_issued;
+    ++e->n_captures;
+    return STX_OK;
+}
+
+int graph_replay(stx_engine *e, TileGraph *g, const TileCall &c, double *loss_out) {
+    // the origins of the content windows for this call (start // scale, roll // scale per layer:
+    // style_transfer.py:572,647-655), re-validated like the eager path does
+    int vals[2 * kMaxDynWindows];
+    int n = 0;
+    for (const DynWindow &w : g->windows) {
+        const int oy = (int)std::floor((double)c.start[0] / w.scale);
+        const int ox = (int)std::floor((double)c.start[1] / w.scale);
+        const int sx = (int)std::floor((double)c.rx / w.scale);
+        const int sy = (int)std::floor((double)c.ry / w.scale);
+        if (oy + w.fh > w.ch || ox + w.fw > w.cw) {
+            set_error("content window [%d+%d, %d+%d] exceeds the %dx%d map of layer %s", oy, w.fh,
+                      ox, w.fw, w.ch, w.cw, w.blob.c_str());
+            return STX_ERR_ARG;
+        }
+        vals[n++] = oy - sy;
+        vals[n++] = ox - sx;
+    }
+    if (n) STX_TRY(set_ints_launch(e->stream, g->dyn, vals, n));
+    Blob &in = e->blobs[e->layers[0].top_blob];
+    const size_t bytes = (size_t)in.channels * c.th * c.tw * sizeof(float);
+    STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, bytes));
+    STX_HIP(hipEventRecord(e->ev_start, e->stream));
+    STX_HIP(hipGraphLaunch(g->exec, e->stream));
+    STX_HIP(hipEventRecord(e->ev_stop, e->stream));
+    e->timed = true;
+    e->flop_algorithmic = g->flop_algorithmic;
+    e->flop_issued = g->flop_issued;
+    STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, bytes));
+    PendingLoss pl;
+    pl.out = loss_out;
+    pl.terms = g->terms;
+    pl.host = g->scalars_host;
     e->pending.push_back(std::move(pl));
+    g->in_flight = true;
+    ++e->n_replays;
+    return STX_OK;
+}
+
+int sc_grad_eager(stx_engine *e, const TileCall &c, double *loss_out) {
+    // the scalar arena holds the reductions of every call queued since the last stx_sync; drain
+    // it (publishing the pending losses) before it could overflow
+    {
+        const size_t per_call = (size_t)c.n_taps * 2100 *
+                                (size_t)std::max(1, e->sh->n_contents + e->sh->n_styles);
+        if (e->scalars_used + per_call > e->scalars_cap) STX_TRY(do_sync(e));
+        if (per_call > e->scalars_cap) {
+            set_error("stx_sc_grad_tile: %d taps need more scalar space than the arena holds", c.n_taps);
+            return STX_ERR_NOMEM;
+        }
+    }
+    TilePlan plan;
+    STX_TRY(sc_grad_prepare(e, c, plan));
+    Blob &in = e->blobs[e->layers[0].top_blob];
+    STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, in.count() * sizeof(float)));
+    PendingLoss pl;
+    pl.out = loss_out;
+    STX_TRY(sc_grad_run(e, c, plan, pl, nullptr));
+    STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, in.count() * sizeof(float)));
+    e->pending.push_back(std::move(pl));
+    ++e->n_eager;
+    return STX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int tw,
+                     const int roll_xy[2], const int start_yx[2], const stx_tap *taps, int n_taps,
+                     double *loss_out, float *grad_out, int grad_mem, int sync_now) {
+    if (!e || !img || th <= 0 || tw <= 0 || !taps || n_taps <= 0 || !grad_out || !start_yx) {
+        set_error("stx_sc_grad_tile: bad arguments");
+        return STX_ERR_ARG;
+    }
+    STX_TRY(e->set_device());
+    const TileCall c{img, img_mem, th, tw, roll_xy ? roll_xy[0] : 0, roll_xy ? roll_xy[1] : 0,
+                     {start_yx[0], start_yx[1]}, taps, n_taps, grad_out, grad_mem};
+    // Recorded launch graphs: a key's first evaluations run eagerly (they size buffers, pack
+    // filter banks and may time kernel variants -- none of which can be recorded), the next one
+    // is recorded, later ones replay the recording for as long as no device buffer moved.
+    // Pageable host memory cannot be copied from inside a recording and profiling needs its
+    // events around every launch group: those calls stay eager.
+    TileGraph *g = nullptr;
+    if (e->graphs_on && !e->profiling && e->side == e->stream && img_mem == STX_DEVICE &&
+        grad_mem == STX_DEVICE) {
+        if (e->graphs.size() > 256) {       // stale recordings of earlier scales
+            const unsigned long now = g_alloc_epoch.load();
+            for (auto it = e->graphs.begin(); it != e->graphs.end();)
+                it = (!it->second->in_flight && it->second->epoch != now) ? e->graphs.erase(it) : ++it;
+        }
+        for (int instance = 0; instance < 64; ++instance) {
+            auto &slot = e->graphs[graph_key(e, c, instance)];
+            if (!slot) slot.reset(new TileGraph);
+            if (!slot->in_flight) {
+                g = slot.get();
+                break;
+            }
+        }
+        if (g && g->disabled) g = nullptr;
+    }
+    int rc;
+    if (!g) {
+        rc = sc_grad_eager(e, c, loss_out);
+    } else {
+        const unsigned long epoch = g_alloc_epoch.load();
+        if (g->epoch != epoch) {        // buffers moved (new scale, larger tile): start over
+            g->destroy_graph();
+            g->eager_calls = 0;
+        }
+        if (!g->exec && g->eager_calls >= e->graph_min_eager) {
+            if (graph_record(e, g, c) != STX_OK) g->disabled = true;   // (stays eager; the error text is kept)
+        }
+        if (g->exec) {
+            rc = graph_replay(e, g, c, loss_out);
+        } else {
+            rc = sc_grad_eager(e, c, loss_out);
+            g->eager_calls += 1;
+            g->epoch = g_alloc_epoch.load();
+        }
+    }
+    STX_TRY(rc);
     if (sync_now) return do_sync(e);
     return STX_OK;
 }

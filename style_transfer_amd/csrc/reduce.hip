@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void content_sums_kernel(const float *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int segs = (w.fw + 63) >> 6;
     const int total_segs = w.C * w.fh * segs;
-    int x_first = (w.ox - w.sx) % w.cw;
+    const int origin_y = content_origin_y(w);
+    int x_first = content_origin_x(w) % w.cw;
     if (x_first < 0) x_first += w.cw;
     // four segments per trip: eight loads in flight per lane (with one segment per trip the kernel
     // was bound by load latency: 2 MB in flight on the whole chip)
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void content_sums_kernel(const float *__restri
             const int gg = g < total_segs ? g : g0;
             const int row = gg / segs, x0 = (gg - row * segs) * 64;
             const int c = row / w.fh, y = row - c * w.fh;
-            int yy = (w.oy + y - w.sy) % w.ch;
+            int yy = (origin_y + y) % w.ch;
             if (yy < 0) yy += w.ch;
             const int x = x0 + lane;
             ok[u] = g < total_segs && x < w.fw;
@@ -151,6 +152,26 @@ __global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__
         const float v = scale * (feat[i] - (content ? content[content_index(w, c, y, x)] : 0.f));
         diff[i] = ACC ? diff[i] + v : v;
     }
+}
+
+// dst[i] = vals[i], i < n <= 16: per-call parameters of a replayed launch graph (values travel
+// as kernel arguments, so no host buffer has to outlive the call).
+struct IntPack16 {
+    int v[16];
+};
+__global__ void set_ints_kernel(int *__restrict__ dst, IntPack16 vals, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
+int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n) {
+    for (int done = 0; done < n; done += 16) {
+        IntPack16 pack{};
+        const int m = std::min(16, n - done);
+        for (int i = 0; i < m; ++i) pack.v[i] = vals[done + i];
+        set_ints_kernel<<<1, 64, 0, s>>>(dst + done, pack, m);
+        STX_CHECK_LAUNCH();
+    }
+    return STX_OK;
 }
 
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,

@@ -120,28 +120,36 @@ class PendingTile:
 class TileEngine:
     """One GPU's worker: the network, its weights and the current targets."""
 
-    def __init__(self, net, device=0, weights=None):
+    def __init__(self, net, device=0, weights=None, share=None):
+        """``share``: an engine on the same GPU whose weights, packed filter banks and targets
+        this one uses (stx_engine_create_shared); ``weights`` is then ignored."""
         assert isinstance(net, NetSpec)
         self.net = net
         self.device = device
         self.handle = None
-        descs = (lib.LayerDesc * len(net.layers))()
         self._names = {}
-        for d, lay in zip(descs, net.layers):
-            d.name = self._cstr(lay.name)
-            d.type = _TYPE_CODES[lay.type]
-            d.bottom = self._cstr(lay.bottom) if lay.bottom else None
-            d.top = self._cstr(lay.top)
-            d.num_output = lay.num_output if lay.type != 'Input' else \
-                (lay.shape[1] if lay.shape else 3)
-            d.kernel_size, d.pad, d.stride = lay.kernel_size, lay.pad, lay.stride
-            d.pool_mode = lib.POOL_AVE if lay.pool == 'AVE' else lib.POOL_MAX
+        self.primary = share.primary if share is not None else self
         handle = ctypes.c_void_p()
-        lib.call('stx_engine_create', device, descs, len(net.layers), ctypes.byref(handle))
+        if share is not None:
+            assert share.device == device and share.net is net
+            lib.call('stx_engine_create_shared', share.handle, ctypes.byref(handle))
+        else:
+            descs = (lib.LayerDesc * len(net.layers))()
+            for d, lay in zip(descs, net.layers):
+                d.name = self._cstr(lay.name)
+                d.type = _TYPE_CODES[lay.type]
+                d.bottom = self._cstr(lay.bottom) if lay.bottom else None
+                d.top = self._cstr(lay.top)
+                d.num_output = lay.num_output if lay.type != 'Input' else \
+                    (lay.shape[1] if lay.shape else 3)
+                d.kernel_size, d.pad, d.stride = lay.kernel_size, lay.pad, lay.stride
+                d.pool_mode = lib.POOL_AVE if lay.pool == 'AVE' else lib.POOL_MAX
+            lib.call('stx_engine_create', device, descs, len(net.layers), ctypes.byref(handle))
         self.handle = handle
+        self._results = []
         self._info = {b: net.layer_info(b) for b in net.blob_names()}
         self.n_styles = 0
-        if weights:
+        if weights and share is None:
             for name, (w, b) in weights.items():
                 self.set_weights(name, w, b)
 
@@ -167,6 +175,24 @@ class TileEngine:
     # ------------------------------------------------------------------------------ basics
     def sync(self):
         lib.call('stx_sync', self.handle)
+        self._results = []
+
+    def keep_until_sync(self, result):
+        """Holds a reference to an object the library will write into at the next sync (a
+        pending loss): it must not be collected before, even if its owner lets go of it."""
+        self._results.append(result)
+        return result
+
+    def wait_for(self, other):
+        """Orders this engine's stream behind what ``other`` has queued so far (no host wait)."""
+        if other is not self:
+            lib.call('stx_engine_wait', self.handle, other.handle)
+
+    def query(self, what):
+        """One of the lib.Q_* counters."""
+        v = ctypes.c_double(0)
+        lib.call('stx_engine_query', self.handle, int(what), ctypes.byref(v))
+        return v.value
 
     def empty(self, shape, dtype=np.float32):
         return DeviceArray(self, shape, dtype)
@@ -308,7 +334,7 @@ class TileEngine:
         roll_c = (ctypes.c_int * 2)(int(roll[0]), int(roll[1])) if roll is not None \
             else (ctypes.c_int * 2)(0, 0)
         start_c = (ctypes.c_int * 2)(int(start[0]), int(start[1]))
-        pending = PendingTile(gkeep, (keep, taps))
+        pending = self.keep_until_sync(PendingTile(gkeep, (keep, taps)))
         lib.call('stx_sc_grad_tile', self.handle, ptr, mem, th, tw, roll_c, start_c, taps, n_taps,
                  ctypes.byref(pending._loss), gptr, gmem, 0)
         return pending

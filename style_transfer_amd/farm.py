@@ -37,6 +37,33 @@ def tile_grid(img_hw, tile_size):
     return rects
 
 
+class LazyLoss:
+    """A loss whose terms are still on their way from the GPUs: pending tile losses and
+    regularizer scalars plus the engines whose ``sync()`` publishes them.  ``float(loss)`` waits
+    (for whatever is not finished yet) and adds them up; until then the step loop keeps queueing
+    work -- one host synchronisation per optimizer step instead of one per term."""
+
+    def __init__(self):
+        self.parts, self.engines, self._value = [], [], None
+
+    def add(self, part, engine):
+        """part: anything with a ``loss`` or ``value`` attribute that is valid after
+        engine.sync()."""
+        assert self._value is None
+        self.parts.append(part)
+        if engine not in self.engines:
+            self.engines.append(engine)
+        return self
+
+    def __float__(self):
+        if self._value is None:
+            for eng in self.engines:
+                eng.sync()
+            self._value = float(sum(p.loss if hasattr(p, 'loss') else p.value for p in self.parts))
+            self.parts, self.engines = [], []
+        return self._value
+
+
 class TileFarm:
     """One host process, one engine per entry of ``devices`` (the reference's ``--devices``)."""
 
@@ -60,13 +87,31 @@ class TileFarm:
         self.weights = weights
         self.max_engines = len(self.devices) * max(1, streams_per_device) \
             if engines is None else len(engines)
-        self.engines = engines if engines is not None else \
-            [TileEngine(net, d, weights) for d in self.devices]
+        # one engine per GPU carries the weights, the packed filter banks and the targets; the
+        # other engines of that GPU (more streams, or the same device listed twice) share them
+        self.engines = engines if engines is not None else []
+        if engines is None:
+            for d in self.devices:
+                self.engines.append(self._new_engine(d))
         self.master = self.engines[0]
         self._targets = None
         self._tiles = {}        # (engine index, slot, th, tw) -> (tile DeviceArray, grad DeviceArray)
         self._staging = {}      # (slot, th, tw) -> master-side staging for remote engines
         self.tile_evals = 0     # tile-iterations executed (the benchmark's unit of work)
+
+    def _new_engine(self, device):
+        for eng in self.engines:
+            if eng.device == device:
+                return TileEngine(self.net, device, share=eng)
+        return TileEngine(self.net, device, self.weights)
+
+    def primaries(self):
+        """The engines that own a GPU's shared state (one per distinct group)."""
+        out = []
+        for eng in self.engines:
+            if eng.primary not in out:
+                out.append(eng.primary)
+        return out
 
     def close(self):
         for bufs in list(self._tiles.values()) + list(self._staging.values()):
@@ -85,15 +130,18 @@ class TileFarm:
         return self.net.layer_info(layer)
 
     def set_weights(self, weights):
-        for e in self.engines:
+        self.weights = weights
+        for e in self.primaries():
             for name, (w, b) in weights.items():
                 e.set_weights(name, w, b)
 
     def set_contents_and_styles(self, contents, styles):
-        """Hands the targets to every engine (TileWorkerPool.set_contents_and_styles,
-        style_transfer.py:309-332)."""
+        """Hands the targets to every GPU, once each (TileWorkerPool.set_contents_and_styles,
+        style_transfer.py:309-332, sends them to every worker process)."""
         self._targets = (contents, styles)
-        for e in self.engines:
+        for e in self.engines:          # nothing of the previous scale may still be running
+            e.sync()
+        for e in self.primaries():
             e.set_contents_and_styles(contents, styles)
 
     def _engines_for(self, n_tiles):
@@ -101,11 +149,8 @@ class TileFarm:
         demand (engine i lives on device i mod n_devices, like the reference's round-robin)."""
         want = min(self.max_engines, max(len(self.devices), n_tiles))
         while len(self.engines) < want and self.owns_engines:
-            eng = TileEngine(self.net, self.devices[len(self.engines) % len(self.devices)],
-                             self.weights)
-            if self._targets is not None:
-                eng.set_contents_and_styles(*self._targets)
-            self.engines.append(eng)
+            # (a further stream of a GPU that already has an engine: shares its state)
+            self.engines.append(self._new_engine(self.devices[len(self.engines) % len(self.devices)]))
         return self.engines[:want]
 
     # ------------------------------------------------------------------ eval_features_once
@@ -242,7 +287,7 @@ class TileFarm:
 
     def eval_sc_grad(self, img, grad, roll, content_layers, style_layers, layer_weights,
                      content_weight, style_weight, tile_size, dd_layers=(), dd_weight=None,
-                     content_roll=None):
+                     content_roll=None, lazy=False):
         """Summed loss and stitched gradient of all tiles (style_transfer.py:614-645).
 
         img, grad: DeviceArray [3,H,W] on the master GPU, both in the UN-rolled frame; ``roll`` is
@@ -250,49 +295,49 @@ class TileFarm:
         ``roll`` after physically rolling the image by it).  ``content_roll`` (default: ``roll``)
         is the shift the engines apply to their content maps; --jitter hands them maps that
         are already in the rolled frame and passes (0, 0) (style_transfer.py:789-798).
-        Returns the loss."""
+
+        Nothing here waits on the host: the master cuts the tiles on its stream, every worker's
+        stream waits for the cuts (an event), pulls its tiles, evaluates them and pushes each
+        gradient back into a master-side buffer on ITS OWN stream; the master's stream waits for
+        each worker's event and stitches.  Workers on other GPUs read and write the master's
+        staging buffers directly (xGMI peer copies, all links at once).
+        Returns the loss: a float (after synchronising), or with ``lazy`` a LazyLoss and the
+        gradient is complete in stream order on the master."""
         if content_roll is None:
             content_roll = roll
         rects = tile_grid(img.shape[-2:], tile_size)
         engines = self._engines_for(len(rects))
         n = len(engines)
-        jobs = []
-        remote = False
+        master = self.master
+        jobs, workers = [], []
         for t, rect in enumerate(rects):
             ei, slot = t % n, t // n
-            th, tw = rect[1] - rect[0], rect[3] - rect[2]
-            tile, tgrad = self._tile_buffers(ei, slot, th, tw)
-            if ei == 0:
-                image_ops.cut_tile(self.master, img, roll, rect, tile)
-                stage = None
-            elif engines[ei].device == self.master.device and not self.force_staging:
-                # another stream of the master GPU: its buffers are directly addressable
-                image_ops.cut_tile(self.master, img, roll, rect, tile)
-                stage = None
-                remote = True
-            else:
-                stage = self._staging_buffers(t, th, tw)
-                image_ops.cut_tile(self.master, img, roll, rect, stage[0])
-                remote = True
-            jobs.append((ei, rect, tile, tgrad, stage))
-        if remote:
-            self.master.sync()      # staged tiles are complete before other GPUs pull them
-        pending = []
-        for ei, rect, tile, tgrad, stage in jobs:
             eng = engines[ei]
-            if stage is not None:
-                tile.copy_from(stage[0])            # peer copy on the worker's stream
-            pending.append(eng.sc_grad_tile_async(
+            th, tw = rect[1] - rect[0], rect[3] - rect[2]
+            if eng.device == master.device and not (self.force_staging and ei != 0):
+                # the master's own GPU (any stream): its buffers are directly addressable
+                tile, tgrad = self._tile_buffers(ei, slot, th, tw)
+            else:
+                tile, tgrad = self._staging_buffers(t, th, tw)
+            image_ops.cut_tile(master, img, roll, rect, tile)
+            if eng is not master and eng not in workers:
+                workers.append(eng)
+            jobs.append((eng, rect, tile, tgrad))
+        for eng in workers:
+            eng.wait_for(master)            # the tiles are cut before anyone reads them
+        loss = LazyLoss()
+        for eng, rect, tile, tgrad in jobs:
+            loss.add(eng.sc_grad_tile_async(
                 tile, (rect[0], rect[2]), content_roll, content_layers, style_layers,
                 layer_weights, content_weight, style_weight, grad_out=tgrad,
-                dd_layers=dd_layers, dd_weight=dd_weight))
-        for eng in engines[1:]:
-            eng.sync()
-        for (ei, rect, tile, tgrad, stage) in jobs:
-            if stage is not None:
-                stage[1].copy_from(tgrad)           # peer copy on the master's stream
-                tgrad = stage[1]
-            image_ops.put_tile(self.master, grad, roll, rect, tgrad)
-        self.master.sync()
+                dd_layers=dd_layers, dd_weight=dd_weight), eng)
+        for eng in workers:
+            master.wait_for(eng)            # that worker's gradients have landed
+        for eng, rect, tile, tgrad in jobs:
+            image_ops.put_tile(master, grad, roll, rect, tgrad)
         self.tile_evals += len(rects)
-        return sum(p.loss for p in pending)
+        if lazy:
+            return loss
+        value = float(loss)
+        master.sync()
+        return value

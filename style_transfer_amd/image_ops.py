@@ -52,8 +52,7 @@ def regularizers(engine, img, grad, mean_bgr, tv_scale, tv_power, p_scale, p_pow
     image, so the un-rolled image meets the auxiliary image displaced by it."""
     _, H, W = img.shape
     mean = (ctypes.c_float * 3)(*[float(m) for m in np.ravel(mean_bgr)])
-    out = PendingScalar()
-    lib.call('stx_image_regularizers', engine.handle, img.ptr, grad.ptr, H, W, mean,
+XX, engine.handle, img.ptr, grad.ptr, H, W, mean,
              float(tv_scale), float(tv_power), float(p_scale), float(p_power),
              aux.ptr if aux is not None else None, float(aux_scale),
              _xy(aux_roll) if aux_roll is not None else None, ctypes.byref(out._v))
@@ -65,7 +64,7 @@ def swt_haar(engine, img, grad, scale, power, roll=None):
     returns a PendingScalar with scale * sum |detail|^power (style_transfer.py:716-720 for the
     default wavelet and level count)."""
     _, H, W = img.shape
-    out = PendingScalar()
+    out = engine.keep_until_sync(PendingScalar())
     lib.call('stx_image_swt_haar', engine.handle, img.ptr, grad.ptr, H, W,
              _xy(roll) if roll is not None else None, float(scale), float(power),
              ctypes.byref(out._v))

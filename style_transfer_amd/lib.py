@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get('STX_LIB') or os.path.join(_HERE, 'csrc', 'libstx.so')
 HOST, DEVICE = 0, 1
 LAYER_INPUT, LAYER_CONV, LAYER_RELU, LAYER_POOL = 0, 1, 2, 3
 POOL_MAX, POOL_AVE = 0, 1
+(Q_SHARED_ENGINES, Q_TARGET_UPLOADS, Q_TARGET_BYTES, Q_WEIGHT_BYTES, Q_GRAPH_CAPTURES,
+ Q_GRAPH_REPLAYS, Q_EAGER_TILES) = range(7)
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -58,6 +60,9 @@ SIGNATURES = {
     'stx_device_count': [c_int_p],
     'stx_device_name': [_i, ctypes.c_char_p, _sz],
     'stx_engine_create': [_i, ctypes.POINTER(LayerDesc), _i, ctypes.POINTER(_vp)],
+    'stx_engine_create_shared': [_vp, ctypes.POINTER(_vp)],
+    'stx_engine_wait': [_vp, _vp],
+    'stx_engine_query': [_vp, _i, c_double_p],
     'stx_set_conv_weights': [_vp, ctypes.c_char_p, _vp, _vp, _i],
     'stx_sync': [_vp],
     'stx_engine_device': [_vp, c_int_p],

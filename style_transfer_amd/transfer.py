@@ -221,7 +221,10 @@ class StyleTransfer:
     # ------------------------------------------------------------------------------ objective
     def eval_loss_and_grad(self, params, sc_args):
         """Loss and gradient of the full image (style_transfer.py:700-736).  ``params`` is the
-        device iterate; returns (loss, device gradient)."""
+        device iterate; returns (loss, device gradient).  Nothing waits on the host here: the
+        loss is a LazyLoss (``float(loss)`` waits for it) and the gradient is complete in stream
+        order on the master GPU, which is all the optimizers need -- the step loop synchronises
+        once per iteration, for its statistics."""
         args = self.args
         (roll, content_layers, style_layers, content_weight, style_weight, dd_layers, dd_weight,
          content_roll) = sc_args
@@ -229,22 +232,20 @@ class StyleTransfer:
         loss = self.farm.eval_sc_grad(params, self.grad, roll, content_layers, style_layers,
                                       self.layer_weights, content_weight, style_weight,
                                       args.tile_size, dd_layers=dd_layers, dd_weight=dd_weight,
-                                      content_roll=content_roll)
+                                      content_roll=content_roll, lazy=True)
         aux_on = self.aux_image is not None
         if args.tv_weight or args.p_weight or aux_on:
             reg = image_ops.regularizers(
                 self.engine, params, self.grad, self.mean, lw * args.tv_weight, args.tv_power,
                 lw * args.p_weight, args.p_power, self.aux_image,
                 lw * args.aux_weight if aux_on else 0.0, aux_roll=roll)
-            self.engine.sync()
-            loss += reg.value
+            loss.add(reg, self.engine)
         if args.swt_weight:
             # style_transfer.py:716-720.  Only the reference's default transform is restated
             # (oracle/num_ops.py): PyWavelets, which it calls, is not part of its tree.
             swt = image_ops.swt_haar(self.engine, params, self.grad, lw * args.swt_weight,
                                      args.swt_power, roll=roll)
-            self.engine.sync()
-            loss += swt.value
+            loss.add(swt, self.engine)
         return loss, self.grad
 
     # --------------------------------------------------------------------------- one scale
@@ -303,6 +304,7 @@ class StyleTransfer:
             avg_img, loss = self.optimizer.update(lambda p: self.eval_loss_and_grad(p, sc_args))
             self.optimizer.roll(-roll)
             update_size, tv_loss = image_ops.step_stats(self.engine, avg_img, self.old_avg)
+            loss = float(loss)              # (everything is finished by now: publishes the terms)
             self.current_raw = avg_img
             self.step_times.append(time.perf_counter() - t0)
             if callback is not None:
