@@ -52,7 +52,8 @@ def regularizers(engine, img, grad, mean_bgr, tv_scale, tv_power, p_scale, p_pow
     image, so the un-rolled image meets the auxiliary image displaced by it."""
     _, H, W = img.shape
     mean = (ctypes.c_float * 3)(*[float(m) for m in np.ravel(mean_bgr)])
-XX, engine.handle, img.ptr, grad.ptr, H, W, mean,
+    out = engine.keep_until_sync(PendingScalar())
+    lib.call('stx_image_regularizers', engine.handle, img.ptr, grad.ptr, H, W, mean,
              float(tv_scale), float(tv_power), float(p_scale), float(p_power),
              aux.ptr if aux is not None else None, float(aux_scale),
              _xy(aux_roll) if aux_roll is not None else None, ctypes.byref(out._v))
