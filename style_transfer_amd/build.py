@@ -24,6 +24,7 @@ SOURCES = {
     'conv_wino2.hip': [],
     'conv_wino4.hip': [],
     'gram.hip': [],
+    'symm.hip': [],
     'pool.hip': [],
     'reduce.hip': [],
     # one rounding per float32 operation, like the reference's numpy expressions
@@ -45,7 +46,8 @@ def _stale(target, deps):
 def _compile(src, extra, force):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
-    deps = [path, os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'stx.h')]
+    deps = [path, os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bf16x3.h'),
+            os.path.join(INCLUDE, 'stx.h')]
     if force or _stale(obj, deps):
         cmd = [HIPCC] + COMMON + extra + ['-c', path, '-o', obj]
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -220,6 +220,14 @@ int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan,
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
                        const float *target, float *dsym, float *sumsq);
 
+// S = dsym F (+ per-workgroup partial sums of |S|) on the bf16 matrix cores, three-piece split
+// (symm.hip).  `pieces` is scratch for the split dsym: symm_pieces_elems(C) 16-bit words.
+size_t symm_pieces_elems(int C);
+int symm_num_workgroups(int C, int HW);
+bool symm_bf3_usable(const float *feat, const float *out, int C, int HW);
+int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
+                    float *out, float *partials, int C, int HW);
+
 // sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
 // content map.
 #ifdef __HIPCC__

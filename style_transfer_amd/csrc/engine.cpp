@@ -195,7 +195,7 @@ struct stx_engine {
     std::shared_ptr<SharedState> sh;   // weights, packed banks, targets (shared per GPU)
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
-    DevBuf gram_partials, gram, dsym, symm_partials, upload;
+    DevBuf gram_partials, gram, dsym, dsym_pieces, symm_partials, upload;
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
     size_t scalars_cap = 0, scalars_used = 0;
@@ -663,6 +663,36 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
     return STX_OK;
 }
 
+// S = sym(tril(G - Gs)) F into `sgrad`, sum |S| into *abs_sum (style_transfer.py:587-593).  The
+// three-piece bf16 kernel where it applies (STX_SYMM=fp32 keeps the fp32-MFMA 1x1 path).
+int launch_symm(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
+                float *sgrad, float *abs_sum) {
+    if (symm_bf3_usable(feat, sgrad, C, h * w)) {
+        const int n_wg = symm_num_workgroups(C, h * w);
+        STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+        STX_TRY(e->dsym_pieces.ensure(symm_pieces_elems(C) * sizeof(unsigned short)));
+        STX_TRY(symm_bf3_launch(stream, feat, e->dsym.f(), static_cast<unsigned short *>(e->dsym_pieces.ptr),
+                                sgrad, e->symm_partials.f(), C, h * w));
+        return sum_partials_launch(stream, e->symm_partials.f(), n_wg, abs_sum);
+    }
+    const ConvConfig cfg = conv_pick_config(1, C, C, h, w);
+    const int n_wg = conv_num_workgroups(cfg, C, h, w);
+    STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+    ConvProblem p{};
+    p.x = feat;
+    p.w = e->dsym.f();
+    p.y = sgrad;
+    p.partials = e->symm_partials.f();
+    p.K = C;
+    p.M = C;
+    p.H = h;
+    p.W = w;
+    p.ksize = 1;
+    p.epilogue = kEpiSymm;
+    STX_TRY(conv_launch(stream, cfg, p, false));
+    return sum_partials_launch(stream, e->symm_partials.f(), n_wg, abs_sum);
+}
+
 int begin_timing(stx_engine *e) {
     STX_HIP(hipEventRecord(e->ev_start, e->stream));
     e->flop_algorithmic = e->flop_issued = 0;
@@ -953,7 +983,7 @@ void stx_engine_destroy(stx_engine *e) {
         for (auto &c : e->sh->contents) c.feat->release();
         for (auto &s : e->sh->styles) s.gram->release();
     }
-    DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->symm_partials,
+    DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->dsym_pieces, &e->symm_partials,
                       &e->upload, &e->scalars, &e->dscalars, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
     if (e->scalars_host) (void)hipHostFree(e->scalars_host);
@@ -1392,25 +1422,9 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                     STX_TRY(gram_finish_launch(e->side, e->gram_partials.f(), plan, nullptr,
                                                st.gram->f(), e->dsym.f(), sc));
                 }
-                // S = sym(tril(G - Gs)) . F  with sum|S| partials
-                const ConvConfig cfg = conv_pick_config(1, C, C, b.h, b.w);
-                const int n_wg = conv_num_workgroups(cfg, C, b.h, b.w);
-                STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
-                ConvProblem p{};
-                p.x = b.data.f();
-                p.w = e->dsym.f();
-                p.y = sgrad;
-                p.partials = e->symm_partials.f();
-                p.K = C;
-                p.M = C;
-                p.H = b.h;
-                p.W = b.w;
-                p.ksize = 1;
-                p.epilogue = kEpiSymm;
                 {
                     ProfScope scope(e, "symm " + b.name, 2.0 * C * C * (double)HW, e->side);
-                    STX_TRY(conv_launch(e->side, cfg, p, false));
-                    STX_TRY(sum_partials_launch(e->side, e->symm_partials.f(), n_wg, sc + 1));
+                    STX_TRY(launch_symm(e, e->side, b.data.f(), C, b.h, b.w, sgrad, sc + 1));
                 }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
                 terms[k].push_back(Term{true, sgrad, sc + 1,
@@ -2088,22 +2102,7 @@ int stx_op_style_terms(stx_engine *e, const float *feat, int C, int h, int w,
     STX_TRY(gram_partials_launch(e->stream, feat, plan, e->gram_partials.f()));
     STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr, gram_target,
                                e->dsym.f(), sc));
-    const ConvConfig cfg = conv_pick_config(1, C, C, h, w);
-    const int n_wg = conv_num_workgroups(cfg, C, h, w);
-    STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
-    ConvProblem p{};
-    p.x = feat;
-    p.w = e->dsym.f();
-    p.y = sgrad;
-    p.partials = e->symm_partials.f();
-    p.K = C;
-    p.M = C;
-    p.H = h;
-    p.W = w;
-    p.ksize = 1;
-    p.epilogue = kEpiSymm;
-    STX_TRY(conv_launch(e->stream, cfg, p, false));
-    STX_TRY(sum_partials_launch(e->stream, e->symm_partials.f(), n_wg, sc + 1));
+    STX_TRY(launch_symm(e, e->stream, feat, C, h, w, sgrad, sc + 1));
     if (normalized_out)
         STX_TRY(inject_style_launch(e->stream, normalized_out, sgrad, count, sc + 1, 1.0f, false));
     STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),

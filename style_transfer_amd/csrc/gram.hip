@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
+#include "bf16x3.h"
 #include "common.h"
 
 namespace stx {
@@ -35,8 +37,11 @@ GramPlan gram_plan(int C, int HW) {
     p.HW = HW;
     const int T = ceil_div(C, kGT);
     p.tiles = T * (T + 1) / 2;
-    int splits = std::max(1, 512 / p.tiles);
-    splits = std::min(splits, ceil_div(HW, 8 * kGP));   // at least eight stages per slice
+    int target = 512, min_stages = 8;
+    if (const char *env = getenv("STX_GRAM_WGS")) target = std::max(1, atoi(env));
+    if (const char *env = getenv("STX_GRAM_MIN_STAGES")) min_stages = std::max(1, atoi(env));
+    int splits = std::max(1, target / p.tiles);
+    splits = std::min(splits, ceil_div(HW, min_stages * kGP));   // at least eight stages per slice
     splits = std::max(splits, 1);
     p.splits = splits;
     p.parts = 1;
@@ -316,11 +321,189 @@ __global__ __launch_bounds__(256, 2) void gram_partial_wide_kernel(const float *
         reinterpret_cast<float4 *>(out)[tid + 256 * n] = reinterpret_cast<const float4 *>(red)[tid + 256 * n];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Gram on the bf16 matrix cores with fp32-class accuracy: three bf16 pieces per operand, six
+// products per step (bf16x3.h has the arithmetic and its error budget).
+//
+// The A / B fragment of the 32x32x16 MFMA is 8 consecutive pixels of one channel row per lane
+// (lane l: channel l & 31, pixels 8 (l >> 5) .. + 7 of the 16-pixel step).  Loading those 32
+// bytes per lane straight from F = [C][h*w] was tried first and is SLOWER than the fp32 kernel
+// (conv1_1: 115 vs 73 us): a wave load then touches 32 different cache lines.  So the tile is
+// staged exactly as in gram_partial_wide_kernel -- coalesced 16-byte loads, fp32 in LDS -- and
+// split into bf16 pieces in registers after the fragment read (5.5 vector instructions per
+// element, issued in the shadow of the bf16 MFMAs, which -- unlike the fp32 MFMA -- leave the
+// vector pipe free).
+#ifndef STX_GRAM_SKIP
+#define STX_GRAM_SKIP 0   // timing experiments (tools/ubench/gram_bench.hip): 1 no MFMAs, 2 no split (raw
+#endif                   // bits as pieces), 4 no loads after the first stage, 8 no LDS stores.  Wrong results.
+__global__ __launch_bounds__(256, 2) void gram_partial_bf3_kernel(const float *__restrict__ F, int C,
+                                                                  int HW, int tiles, int slice,
+                                                                  unsigned f_bytes,
+                                                                  float *__restrict__ partials) {
+    // two stages of [A tile | B tile] in LDS: stage s + 1 is written while stage s is multiplied,
+    // one barrier per stage, and the loads of stage s + 2 are in flight for a whole stage
+    constexpr int kStageFloats = 2 * kGT * kGLdW;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // XCD-aware order, as gram_partial_wide_kernel
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int tile = L % tiles, split = L / tiles;
+    int ti, tj;
+    tile_coords(tile, ti, tj);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    const bool diag = ti == tj;
+    const int p_begin = split * slice;
+    const int p_end = min(HW, p_begin + slice);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging exactly as gram_partial_wide_kernel: fp32 tiles [64 channels][64 pixels + 4] in LDS,
+    // coalesced 16-byte buffer loads (a wave covers 4 channel rows x 256 bytes)
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, f_bytes, 0x00020000);
+    unsigned aoff[4], boff[4];
+    int ldst[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;                 // float4 index in the 64 x 16 tile
+        const int ch = e >> 4, px = (e & 15) * 4;
+        const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+        aoff[n] = ca < C ? (unsigned)(ca * HW + px) * 4u : kOob;
+        boff[n] = cb < C && !diag ? (unsigned)(cb * HW + px) * 4u : kOob;
+        ldst[n] = ch * kGLdW + px;
+    }
+    u32x4g ra[4], rb[4];
+    auto load = [&](int p0) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(p0 * 4);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ra[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, aoff[n], so, 0);
+        if (!diag) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rb[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, boff[n], so, 0);
+        }
+    };
+    auto store = [&](int p0, int buf) {
+        float *At = lds + buf * kStageFloats, *Bt = At + kGT * kGLdW;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int rem = p_end - (p0 + ((tid + 256 * n) & 15) * 4);
+            u32x4g va = ra[n], vb = rb[n];
+            if (rem < 4) {
+                va.x = rem > 0 ? va.x : 0u, va.y = rem > 1 ? va.y : 0u, va.z = rem > 2 ? va.z : 0u, va.w = 0u;
+                vb.x = rem > 0 ? vb.x : 0u, vb.y = rem > 1 ? vb.y : 0u, vb.z = rem > 2 ? vb.z : 0u, vb.w = 0u;
+            }
+            *reinterpret_cast<u32x4g *>(At + ldst[n]) = va;
+            if (!diag) *reinterpret_cast<u32x4g *>(Bt + ldst[n]) = vb;
+        }
+    };
+
+    // Fragments: wave w takes pixels 16 w .. 16 w + 15 of the stage as ONE 32x32x16 step; lane half h
+    // holds pixels 8 h .. 8 h + 7 of it (two 16-byte LDS reads per 32-channel block), splits them
+    // into the three bf16 pieces in registers and feeds all four output blocks of the tile.
+    const int a_off = l31 * kGLdW + wave * 16 + half * 8;
+    const int b_off = (diag ? 0 : kGT * kGLdW) + a_off;
+    auto fragment = [&](const float *q, bf16x8 (&pc)[3]) {
+        const f32x4g lo = *reinterpret_cast<const f32x4g *>(q);
+        const f32x4g hi = *reinterpret_cast<const f32x4g *>(q + 4);
+        const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (STX_GRAM_SKIP & 2) {
+            typedef float f32x4s __attribute__((ext_vector_type(4)));
+            pc[0] = __builtin_bit_cast(bf16x8, (f32x4s){x[0], x[1], x[2], x[3]});
+            pc[1] = __builtin_bit_cast(bf16x8, (f32x4s){x[4], x[5], x[6], x[7]});
+            pc[2] = pc[0];
+        } else {
+            split3_bf16(x, pc[0], pc[1], pc[2]);
+        }
+    };
+
+    if (p_begin < p_end) {
+        load(p_begin);
+        store(p_begin, 0);
+        if (p_begin + kGP < p_end) load(p_begin + kGP);
+        __syncthreads();
+        int buf = 0;
+        for (int p0 = p_begin; p0 < p_end; p0 += kGP, buf ^= 1) {
+            const float *base = lds + buf * kStageFloats;
+            bf16x8 pa[2][3], pb[2][3];
+            fragment(base + a_off, pa[0]);
+            fragment(base + a_off + 32 * kGLdW, pa[1]);
+            if (!diag) {
+                fragment(base + b_off, pb[0]);
+                fragment(base + b_off + 32 * kGLdW, pb[1]);
+            }
+            // the other buffer was last read in the previous stage, which every wave has left
+            if (p0 + kGP < p_end && !(STX_GRAM_SKIP & 8)) store(p0 + kGP, buf ^ 1);
+            if (p0 + 2 * kGP < p_end && !(STX_GRAM_SKIP & 4)) load(p0 + 2 * kGP);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (diag && j > i) continue;      // upper block of a diagonal tile
+                    if (STX_GRAM_SKIP & 1) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc[i][j][q] += (float)(pa[i][q][0] + (diag ? pa[j] : pb[j])[q][1]);
+                        continue;
+                    }
+                    acc[i][j] = mfma_split6(pa[i], diag ? pa[j] : pb[j], acc[i][j]);
+                }
+            __syncthreads();
+        }
+    }
+    // add the four waves' partial tiles in wave order through LDS (deterministic), then one
+    // coalesced write of the 64x64 tile
+    float *red = lds;                                  // 64 x 64 floats fit in a stage
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float *q = red + row * kGT + j * 32 + l31;
+                        *q = w == 0 ? acc[i][j][r] : *q + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        reinterpret_cast<float4 *>(out)[tid + 256 * n] = reinterpret_cast<const float4 *>(red)[tid + 256 * n];
+}
+
+// STX_GRAM=fp32 (read at every call) keeps the fp32-MFMA kernels, for A/B measurements and tests.
+static bool gram_use_bf3() {
+    const char *env = getenv("STX_GRAM");
+    return !(env && !strcmp(env, "fp32"));
+}
+
 int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials) {
     int slice = ceil_div(plan.HW, plan.splits);
     slice = ceil_div(slice, kGP) * kGP;
     const bool aligned = (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
     const double bytes = 4.0 * plan.C * (double)plan.HW;
+    if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && gram_use_bf3()) {
+        gram_partial_bf3_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
+            feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, partials);
+        STX_CHECK_LAUNCH();
+        return STX_OK;
+    }
     // (buffer loads need dword alignment only: odd plane sizes take the wide kernel too)
     if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && !getenv("STX_GRAM_NARROW")) {
         gram_partial_wide_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(

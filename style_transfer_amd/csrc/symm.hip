@@ -1,0 +1,224 @@
+// S = sym(tril(G - Gs)) F with the partial sums of |S|: the SSYMM of the style gradient
+// (num_utils.py:59-66, style_transfer.py:587-593) on the bf16 matrix cores with fp32-class
+// accuracy -- three bf16 pieces per operand, six products per step (bf16x3.h).
+//
+// The product is a tall-skinny GEMM: M = C output channels, N = h*w pixels (up to 2^20),
+// K = C.  The fp32-MFMA form of it (the 1x1 path of conv_mfma_kernel) needed 393 us per
+// 1024 x 1024 tile for the five style layers: 0.42-0.62 of the fp32 matrix pipe on the deep
+// layers, 4.3 TB/s on conv1_1.  Here:
+//   * D arrives already split (gram_finish_kernel writes the three bf16 piece matrices next to
+//     the fp32 one), a 64-row x 32-k chunk of it is staged through LDS for the four waves of a
+//     workgroup, double buffered, one barrier per chunk;
+//   * F never touches LDS: the B fragment of v_mfma_f32_32x32x16_bf16 is 8 consecutive k
+//     (channels) of one pixel per lane (lane l: pixel l & 31, channels 8 (l >> 5) .. + 7 of the
+//     16-channel step) -- eight dword loads whose lanes walk the pixel axis, i.e. 128-byte row
+//     segments of F = [C][h*w], straight into registers, split there, loads two steps ahead;
+//   * a wave owns 64 channels x 64 pixels of S (four 32x32 blocks), a workgroup 64 x 256; the
+//     channel tiles of one pixel tile run on one XCD (they read the same columns of F).
+// Sums of |S| are added per lane, per wave, per workgroup in a fixed order (deterministic).
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "bf16x3.h"
+#include "common.h"
+
+namespace stx {
+
+namespace {
+
+constexpr int kSM = 64;            // output channels per workgroup
+constexpr int kSN = 256;           // pixels per workgroup (64 per wave)
+constexpr int kSK = 32;            // k per LDS chunk (two MFMA steps)
+constexpr int kRowBytes = 80;      // 32 bf16 + 16 bytes of padding: conflict-free ds_read_b128
+constexpr int kPieceBytes = kSM * kRowBytes;
+constexpr int kChunkBytes = 3 * kPieceBytes;
+
+typedef unsigned u32x4y __attribute__((ext_vector_type(4)));
+
+}  // namespace
+
+size_t symm_pieces_elems(int C) {
+    const size_t cp = (size_t)ceil_div(C, kSM) * kSM;
+    return 3 * cp * cp;
+}
+
+__global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restrict__ F,
+                                                          const unsigned short *__restrict__ Dp,
+                                                          float *__restrict__ S,
+                                                          float *__restrict__ partials, int C, int Cp,
+                                                          int HW, unsigned f_bytes, int m_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes];
+    __shared__ float wave_sum[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, g = lane >> 5;
+    // XCD-aware order (workgroup b runs on XCD b & 7): an XCD takes a contiguous range of work
+    // items, channel tile fastest
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mt = __builtin_amdgcn_readfirstlane(L % m_tiles), pt = __builtin_amdgcn_readfirstlane(L / m_tiles);
+    const int m0 = mt * kSM;
+    const int px0 = pt * kSN + wave * 64;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(S, 0, f_bytes, 0x00020000);
+    // per-lane byte offsets of the two pixel blocks (k group g starts 8 rows further down)
+    unsigned voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int px = px0 + j * 32 + l31;
+        voff[j] = px < HW ? (unsigned)((g * 8) * HW + px) * 4u : kOob;
+    }
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const int n_steps = Cp / 16, n_chunks = Cp / kSK;
+
+    // ---- D chunk staging: 3 pieces x 64 rows x 64 bytes = 768 16-byte segments, three per thread
+    const unsigned short *dsrc[3];
+    unsigned ddst[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int row = tid >> 2, seg = tid & 3;
+        dsrc[n] = Dp + ((size_t)n * Cp + (m0 + row)) * Cp + seg * 8;
+        ddst[n] = (unsigned)(n * kPieceBytes + row * kRowBytes + seg * 16);
+    }
+    u32x4y dreg[3];
+    auto d_load = [&](int chunk) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) dreg[n] = *reinterpret_cast<const u32x4y *>(dsrc[n] + chunk * kSK);
+    };
+    auto d_store = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<u32x4y *>(lds + buf * kChunkBytes + ddst[n]) = dreg[n];
+    };
+
+    // ---- F fragments: step s covers channels 16 s .. 16 s + 15
+    float raw[3][2][8];       // ring of three steps in flight (two ahead of the one being multiplied)
+    auto f_load = [&](int step, int slot_) {
+        // (a scalar offset must not exceed the descriptor's range: channels past C are clamped to
+        // C, where every lane is out of range and reads zero)
+        const int k0 = __builtin_amdgcn_readfirstlane(step * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                raw[slot_][j][e] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rf, voff[j], (unsigned)min(k0 + e, C) * HW4, 0));
+    };
+
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    d_load(0);
+    f_load(0, 0);
+    if (n_steps > 1) f_load(1, 1);
+    d_store(0);
+    if (n_chunks > 1) d_load(1);
+    __syncthreads();
+
+    const unsigned a_off = (unsigned)(l31 * kRowBytes + g * 16);
+    auto do_step = [&](int step, int slot_, int buf, int s_in_chunk) {
+        bf16x8 pb[2][3], pa[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) split3_bf16(raw[slot_][j], pb[j][0], pb[j][1], pb[j][2]);
+        const unsigned char *base = lds + buf * kChunkBytes + a_off + s_in_chunk * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+                pa[i][n] = *reinterpret_cast<const bf16x8 *>(base + n * kPieceBytes + i * 32 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split6(pa[i], pb[j], acc[i][j]);
+    };
+
+    // three steps per trip so that the ring slot is a compile-time constant; a chunk is two steps
+    int step = 0;
+    auto advance = [&](int slot_) {
+        const int chunk = step >> 1, s_in = step & 1, buf = chunk & 1;
+        if (step + 2 < n_steps) f_load(step + 2, (slot_ + 2) % 3);
+        do_step(step, slot_, buf, s_in);
+        if (s_in == 1) {
+            // the other buffer was last read in the previous chunk, which every wave has left
+            if (chunk + 1 < n_chunks) d_store(buf ^ 1);
+            if (chunk + 2 < n_chunks) d_load(chunk + 2);
+            __syncthreads();
+        }
+        ++step;
+    };
+    while (step < n_steps) {
+        advance(0);
+        if (step < n_steps) advance(1);
+        if (step < n_steps) advance(2);
+    }
+
+    // ---- S tile out, |S| summed: D register r of a block is row (r & 3) + 8 (r >> 2) + 4 g
+    float asum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const unsigned so = (unsigned)min(__builtin_amdgcn_readfirstlane(m0 + i * 32 + (r & 3) + 8 * (r >> 2)), C) * HW4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = px0 + j * 32 + l31;
+                const bool ok = row < C && px < HW;
+                const float v = acc[i][j][r];
+                asum += ok ? fabsf(v) : 0.f;
+                const unsigned vo = ok ? (unsigned)((4 * g) * HW + px) * 4u : kOob;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0);
+            }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    if (lane == 0) wave_sum[wave] = asum;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
+}
+
+// dsym [C][C] fp32 -> pieces [3][Cp][Cp] bf16 (zero padded to a multiple of 64)
+__global__ void symm_split_kernel(const float *__restrict__ dsym, int C, int Cp,
+                                  unsigned short *__restrict__ pieces) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cp * Cp) return;
+    const int i = idx / Cp, j = idx - i * Cp;
+    unsigned short s1 = 0, s2 = 0, s3 = 0;
+    if (i < C && j < C) split3_bf16_scalar(dsym[i * C + j], s1, s2, s3);
+    pieces[idx] = s1;
+    pieces[(size_t)Cp * Cp + idx] = s2;
+    pieces[2 * (size_t)Cp * Cp + idx] = s3;
+}
+
+int symm_num_workgroups(int C, int HW) { return ceil_div(C, kSM) * ceil_div(HW, kSN); }
+
+bool symm_bf3_usable(const float *feat, const float *out, int C, int HW) {
+    const char *env = getenv("STX_SYMM");
+    if (env && !strcmp(env, "fp32")) return false;
+    const double bytes = 4.0 * C * (double)HW;
+    return bytes < 2147483648.0 && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
+}
+
+int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
+                    float *out, float *partials, int C, int HW) {
+    const int Cp = ceil_div(C, kSM) * kSM;
+    symm_split_kernel<<<ceil_div(Cp * Cp, 256), 256, 0, s>>>(dsym, C, Cp, pieces);
+    STX_CHECK_LAUNCH();
+    const int m_tiles = Cp / kSM;
+    symm_bf3_kernel<<<symm_num_workgroups(C, HW), 256, 0, s>>>(
+        feat, pieces, out, partials, C, Cp, HW, (unsigned)(4.0 * C * (double)HW), m_tiles);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+}  // namespace stx

@@ -150,6 +150,11 @@ class StyleTransfer:
             raise NotImplementedError('--swt-wavelet %s --swt-levels %s: only the default '
                                       '(haar, 1 level) is implemented'
                                       % (args.swt_wavelet, args.swt_levels))
+        if callable(raw) or raw:
+            import warnings
+            warnings.warn('--swt-weight: the Haar SWT term is a restatement of PyWavelets\' '
+                          'swt2 / iswt2, which is not part of the reference tree and not '
+                          'installed here; it has never been compared with it (parity unpinned)')
 
     # ----------------------------------------------------------------------- image <-> params
     def pil_to_image(self, img):
