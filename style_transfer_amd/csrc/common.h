@@ -217,16 +217,21 @@ GramPlan gram_plan(int C, int HW);
 int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials);
 // gram_out (lower-tri, upper zero) = sum_s partials * 1/(C*HW).  If target != null also writes
 // dsym = sym(tril(gram - target)) and sumsq[0] = sum over the lower triangle of (gram-target)^2.
+// `pieces` (optional, with target): dsym split into three bf16 matrices [3][C][C] for symm_bf3_launch
+// (C a multiple of 64).  sumsq == null: the per-block sums of squares are left behind the Gram
+// partials (gram_finish_blocks(plan) floats at partials + plan.partial_floats) for the caller to add.
+int gram_finish_blocks(const GramPlan &plan);
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
-                       const float *target, float *dsym, float *sumsq);
+                       const float *target, float *dsym, float *sumsq, unsigned short *pieces = nullptr);
 
 // S = dsym F (+ per-workgroup partial sums of |S|) on the bf16 matrix cores, three-piece split
 // (symm.hip).  `pieces` is scratch for the split dsym: symm_pieces_elems(C) 16-bit words.
 size_t symm_pieces_elems(int C);
 int symm_num_workgroups(int C, int HW);
 bool symm_bf3_usable(const float *feat, const float *out, int C, int HW);
+// pieces_ready: gram_finish_launch already wrote them (else they are made from dsym here)
 int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
-                    float *out, float *partials, int C, int HW);
+                    bool pieces_ready, float *out, float *partials, int C, int HW);
 
 // sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
 // content map.
@@ -256,6 +261,8 @@ int inject_content_launch(hipStream_t s, float *diff, const float *feat, const f
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
 int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
+int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,
+                         float *out_b);
 
 // image_ops.hip
 int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int ry, int y0, int x0,

@@ -637,6 +637,7 @@ int wino4_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.relu = p.relu;
     a.inj = p.inject;
     a.pool_out = nullptr;
+    a.pool_codes = nullptr;       // (this kernel never writes window codes: engine.cpp conv_writes_pool_codes)
     a.pool_mode = p.pool_mode;
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);

@@ -511,6 +511,10 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
     return conv_launch(e->stream, cfg, p, true);
 }
 
+// Which fused-pooling kernels also leave the window codes the backward pooling runs from: the
+// eight-wave 2-D Winograd kernel does, the four-wave one (ids 210+) writes the pooled values only.
+static bool conv_writes_pool_codes(const ConvConfig &cfg) { return cfg.id >= 200 && cfg.id < 210; }
+
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
     return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
@@ -549,7 +553,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         pt.codes_valid = false;
         if (conv_fuses_pool(cfg, p)) {
             *pooled = true;
-            if (cfg.id < 210 && e->pool_codes) {       // (the four-wave kernel does not write them)
+            if (conv_writes_pool_codes(cfg) && e->pool_codes) {
                 STX_TRY(pt.codes.ensure(pt.count()));
                 p.pool_codes = static_cast<unsigned char *>(pt.codes.ptr);
                 pt.codes_valid = true;
@@ -645,18 +649,20 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
         } else if ((int)li == pooled_layer) {
             continue;
         } else {
-            ProfScope scope(e, "fwd " + L.name, 0.0);
-            unsigned char *codes = nullptr;
-            t.codes_valid = false;
-            if (e->pool_codes) {
-                STX_TRY(t.codes.ensure(t.count()));
-                codes = static_cast<unsigned char *>(t.codes.ptr);
-                t.codes_valid = true;
-            }
-            STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
-                                        t.data.f(), codes));
-            if (t.relu || L.top_blob == relu_blob)
-                STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
+            {
+                ProfScope scope(e, "fwd " + L.name, 0.0);
+                unsigned char *codes = nullptr;
+                t.codes_valid = false;
+                if (e->pool_codes) {
+                    STX_TRY(t.codes.ensure(t.count()));
+                    codes = static_cast<unsigned char *>(t.codes.ptr);
+                    t.codes_valid = true;
+                }
+                STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
+                                            t.data.f(), codes));
+                if (t.relu || L.top_blob == relu_blob)
+                    STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
+            }   // (the loss terms of a tapped pooled blob are timed under their own labels)
             if (after_blob) STX_TRY((*after_blob)(L.top_blob));
         }
     }
@@ -665,15 +671,33 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
 
 // S = sym(tril(G - Gs)) F into `sgrad`, sum |S| into *abs_sum (style_transfer.py:587-593).  The
 // three-piece bf16 kernel where it applies (STX_SYMM=fp32 keeps the fp32-MFMA 1x1 path).
-int launch_symm(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
-                float *sgrad, float *abs_sum) {
-    if (symm_bf3_usable(feat, sgrad, C, h * w)) {
-        const int n_wg = symm_num_workgroups(C, h * w);
+// Style terms of one tapped blob, the launches of style_transfer.py:584-593 in order: Gram of
+// `feat` -> D = G - target (fp32 + bf16 pieces) -> S = sym(D) feat into `sgrad`;
+// sc[0] = sum of squares of tril(D), sc[1] = sum |S| (one small launch for both).
+int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
+                       const float *target, float *sgrad, float *sc, const std::string &name) {
+    const int HW = h * w;
+    const GramPlan plan = gram_plan(C, HW);
+    const int fin_blocks = gram_finish_blocks(plan);
+    STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
+    STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
+    const bool bf3 = symm_bf3_usable(feat, sgrad, C, HW);
+    if (bf3) STX_TRY(e->dsym_pieces.ensure(symm_pieces_elems(C) * sizeof(unsigned short)));
+    unsigned short *pieces = bf3 && C % 64 == 0 ? static_cast<unsigned short *>(e->dsym_pieces.ptr) : nullptr;
+    {
+        ProfScope scope(e, "gram " + name, 2.0 * C * C * (double)HW, stream);
+        STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f()));
+        STX_TRY(gram_finish_launch(stream, e->gram_partials.f(), plan, nullptr, target, e->dsym.f(),
+                                   nullptr, pieces));
+    }
+    ProfScope scope(e, "symm " + name, 2.0 * C * C * (double)HW, stream);
+    const float *block_sumsq = e->gram_partials.f() + plan.partial_floats;
+    if (bf3) {
+        const int n_wg = symm_num_workgroups(C, HW);
         STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
-        STX_TRY(e->dsym_pieces.ensure(symm_pieces_elems(C) * sizeof(unsigned short)));
         STX_TRY(symm_bf3_launch(stream, feat, e->dsym.f(), static_cast<unsigned short *>(e->dsym_pieces.ptr),
-                                sgrad, e->symm_partials.f(), C, h * w));
-        return sum_partials_launch(stream, e->symm_partials.f(), n_wg, abs_sum);
+                                pieces != nullptr, sgrad, e->symm_partials.f(), C, HW));
+        return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
     }
     const ConvConfig cfg = conv_pick_config(1, C, C, h, w);
     const int n_wg = conv_num_workgroups(cfg, C, h, w);
@@ -690,7 +714,7 @@ int launch_symm(stx_engine *e, hipStream_t stream, const float *feat, int C, int
     p.ksize = 1;
     p.epilogue = kEpiSymm;
     STX_TRY(conv_launch(stream, cfg, p, false));
-    return sum_partials_launch(stream, e->symm_partials.f(), n_wg, abs_sum);
+    return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
 }
 
 int begin_timing(stx_engine *e) {
@@ -1408,24 +1432,13 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                               C);
                     return STX_ERR_UNSUPPORTED;
                 }
-                const GramPlan plan = gram_plan(C, HW);
-                const size_t fin_blocks = ceil_div(C * C, 64);
-                STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
-                STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
                 float *sgrad = e->sgrad_tap[k]->f() + (size_t)slot++ * b.count();
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
                 float *sc = e->arena_dev + si;   // [0] = sum tril(D)^2, [1] = sum |S|
-                {
-                    ProfScope scope(e, "gram " + b.name, 2.0 * C * C * (double)HW, e->side);
-                    STX_TRY(gram_partials_launch(e->side, b.data.f(), plan, e->gram_partials.f()));
-                    STX_TRY(gram_finish_launch(e->side, e->gram_partials.f(), plan, nullptr,
-                                               st.gram->f(), e->dsym.f(), sc));
-                }
-                {
-                    ProfScope scope(e, "symm " + b.name, 2.0 * C * C * (double)HW, e->side);
-                    STX_TRY(launch_symm(e, e->side, b.data.f(), C, b.h, b.w, sgrad, sc + 1));
-                }
+                STX_TRY(launch_style_terms(e, e->side, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
+                                           b.name));
+                (void)HW;
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
                 terms[k].push_back(Term{true, sgrad, sc + 1,
                                         (float)(lw * tp.t->style_weight / e->sh->n_styles), ContentWindow{}});
@@ -2089,20 +2102,13 @@ int stx_op_style_terms(stx_engine *e, const float *feat, int C, int h, int w,
     const int HW = h * w;
     const size_t count = (size_t)C * HW;
     // the launches of the style branch of stx_sc_grad_tile, in the same order
-    const GramPlan plan = gram_plan(C, HW);
-    const size_t fin_blocks = ceil_div(C * C, 64);
-    STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
-    STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
     STX_TRY(e->upload.ensure(count * sizeof(float)));
     float *sgrad = s_out ? s_out : e->upload.f();
     STX_TRY(do_sync(e));
     size_t si;
     STX_TRY(alloc_scalars(e, 2, &si));
     float *sc = e->scalars.f() + si;
-    STX_TRY(gram_partials_launch(e->stream, feat, plan, e->gram_partials.f()));
-    STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, nullptr, gram_target,
-                               e->dsym.f(), sc));
-    STX_TRY(launch_symm(e, e->stream, feat, C, h, w, sgrad, sc + 1));
+    STX_TRY(launch_style_terms(e, e->stream, feat, C, h, w, gram_target, sgrad, sc, "op"));
     if (normalized_out)
         STX_TRY(inject_style_launch(e->stream, normalized_out, sgrad, count, sc + 1, 1.0f, false));
     STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),

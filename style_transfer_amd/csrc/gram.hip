@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
                                                           float *__restrict__ gram,
                                                           const float *__restrict__ target,
                                                           float *__restrict__ dsym,
-                                                          float *__restrict__ block_sumsq) {
+                                                          float *__restrict__ block_sumsq,
+                                                          unsigned short *__restrict__ pieces) {
     __shared__ float lane_sum[4][64];
     __shared__ float red[64];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -577,6 +578,16 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
                 const float d = g - target[i * C + j];
                 dsym[idx] = d;
                 if (i != j) dsym[j * C + i] = d;
+                if (pieces) {       // the SYMM kernel's left operand, already split (bf16x3.h)
+                    unsigned short s1, s2, s3;
+                    split3_bf16_scalar(d, s1, s2, s3);
+                    const size_t cc = (size_t)C * C;
+                    pieces[idx] = s1, pieces[cc + idx] = s2, pieces[2 * cc + idx] = s3;
+                    if (i != j) {
+                        const int m = j * C + i;
+                        pieces[m] = s1, pieces[cc + m] = s2, pieces[2 * cc + m] = s3;
+                    }
+                }
                 sq = d * d;
             }
         } else if (gram) {
@@ -615,16 +626,46 @@ int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out)
     return STX_OK;
 }
 
+// two independent sums in one launch (workgroup 0: a, workgroup 1: b), each in the fixed order of
+// sum_partials_kernel: a dispatch costs ~4.5 us however little it does, and a style layer's two
+// scalars (sum of squares of G - Gs, sum |S|) are both only needed after the SYMM product
+__global__ void sum_partials2_kernel(const float *__restrict__ a, int na, float *__restrict__ out_a,
+                                     const float *__restrict__ b, int nb, float *__restrict__ out_b) {
+    __shared__ float red[256];
+    const float *partials = blockIdx.x ? b : a;
+    const int n = blockIdx.x ? nb : na;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) (blockIdx.x ? out_b : out_a)[0] = red[0];
+}
+
+int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,
+                         float *out_b) {
+    sum_partials2_kernel<<<2, 256, 0, s>>>(a, na, out_a, b, nb, out_b);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int gram_finish_blocks(const GramPlan &plan) { return ceil_div(plan.C * plan.C, 64); }
+
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
-                       const float *target, float *dsym, float *sumsq) {
-    const int blocks = ceil_div(plan.C * plan.C, 64);
+                       const float *target, float *dsym, float *sumsq, unsigned short *pieces) {
+    const int blocks = gram_finish_blocks(plan);
     // block partial sums live behind the Gram partials (the caller sizes the buffer for both)
     float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
     const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
     gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits * plan.parts, scale,
-                                              gram_out, target, dsym, block_sumsq);
+                                              gram_out, target, dsym, block_sumsq,
+                                              target ? pieces : nullptr);
     STX_CHECK_LAUNCH();
-    if (target) STX_TRY(sum_partials_launch(s, block_sumsq, blocks, sumsq));
+    // sumsq == null: the caller adds the block partials (behind the Gram partials) up itself
+    if (target && sumsq) STX_TRY(sum_partials_launch(s, block_sumsq, blocks, sumsq));
     return STX_OK;
 }
 

@@ -7,8 +7,9 @@
 // 1024 x 1024 tile for the five style layers: 0.42-0.62 of the fp32 matrix pipe on the deep
 // layers, 4.3 TB/s on conv1_1.  Here:
 //   * D arrives already split (gram_finish_kernel writes the three bf16 piece matrices next to
-//     the fp32 one), a 64-row x 32-k chunk of it is staged through LDS for the four waves of a
-//     workgroup, double buffered, one barrier per chunk;
+//     the fp32 one; symm_split_kernel does it for callers that only have the fp32 matrix, or a
+//     channel count that is not a multiple of 64), a 64-row x 32-k chunk of it is staged through
+//     LDS for the four waves of a workgroup, double buffered, one barrier per chunk;
 //   * F never touches LDS: the B fragment of v_mfma_f32_32x32x16_bf16 is 8 consecutive k
 //     (channels) of one pixel per lane (lane l: pixel l & 31, channels 8 (l >> 5) .. + 7 of the
 //     16-channel step) -- eight dword loads whose lanes walk the pixel axis, i.e. 128-byte row
@@ -210,10 +211,12 @@ bool symm_bf3_usable(const float *feat, const float *out, int C, int HW) {
 }
 
 int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
-                    float *out, float *partials, int C, int HW) {
+                    bool pieces_ready, float *out, float *partials, int C, int HW) {
     const int Cp = ceil_div(C, kSM) * kSM;
-    symm_split_kernel<<<ceil_div(Cp * Cp, 256), 256, 0, s>>>(dsym, C, Cp, pieces);
-    STX_CHECK_LAUNCH();
+    if (!pieces_ready || Cp != C) {
+        symm_split_kernel<<<ceil_div(Cp * Cp, 256), 256, 0, s>>>(dsym, C, Cp, pieces);
+        STX_CHECK_LAUNCH();
+    }
     const int m_tiles = Cp / kSM;
     symm_bf3_kernel<<<symm_num_workgroups(C, HW), 256, 0, s>>>(
         feat, pieces, out, partials, C, Cp, HW, (unsigned)(4.0 * C * (double)HW), m_tiles);
