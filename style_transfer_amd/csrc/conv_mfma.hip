@@ -695,7 +695,10 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     const int y0 = sgpr((blockIdx.x / a.tiles_x) * PR), x0 = sgpr((blockIdx.x % a.tiles_x) * PC);
     const int HW = a.H * a.W;
     constexpr unsigned kOob = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+    // x_bytes == 0: a plane set of 2 GiB or more -- the descriptor is moved to each chunk's KC
+    // planes instead of reaching them through the 32-bit offset
+    const bool big = a.x_bytes == 0;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
@@ -714,7 +717,14 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     u32x4 wreg;
     auto load_stage = [&](int chunk) {
         wreg = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (unsigned)chunk * (W_FLOATS * 4u), 0);
-        const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * (unsigned)(KC * HW) * 4u));
+        unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * (unsigned)(KC * HW) * 4u));
+        if (big) {
+            const int k0 = sgpr(chunk * KC);
+            const int nk = a.K - k0 < KC ? a.K - k0 : KC;
+            rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)k0 * (size_t)HW, 0,
+                                                   (nk > 0 ? nk : 0) * HW * 4, 0x00020000);
+            xs = 0;
+        }
 #pragma unroll
         for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
     };
@@ -810,8 +820,10 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
         return STX_ERR_ARG;
     }
     const double xb = 4.0 * K * (double)H * W;
-    if (xb >= 2147483648.0) {
-        set_error("conv_small_launch: plane set exceeds the 2 GiB buffer-addressing limit");
+    const char *force_big = getenv("STX_WINO_BIG");
+    const bool big = xb >= 2147483648.0 || (force_big && atoi(force_big) == 1);
+    if (4.0 * kSmallKC * (double)H * W >= 2147483648.0) {
+        set_error("conv_small_launch: a %d x %d plane is beyond the buffer-addressing limit", H, W);
         return STX_ERR_UNSUPPORTED;
     }
     SmallConvArgs a;
@@ -825,7 +837,7 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
     a.W = W;
     a.n_chunks = ceil_div(K, kSmallKC);
     a.tiles_x = ceil_div(W, 64);
-    a.x_bytes = (int)xb;
+    a.x_bytes = big ? 0 : (int)xb;
     a.w_bytes = (int)(conv_small_packed_floats(K) * 4);
     const int n_wg = a.tiles_x * ceil_div(H, kSmallPR);
     conv3x3_m4_kernel<kSmallKC, kSmallPR><<<n_wg, 256, 0, s>>>(a);

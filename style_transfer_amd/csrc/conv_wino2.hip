@@ -77,7 +77,13 @@ __device__ __forceinline__ void lds_barrier() {
 
 }  // namespace
 
-template <int EPI, int TXW>
+// BIG: plane sets of 2 GiB and more (a 64-channel blob of a tile larger than 2896 x 2896).  The
+// kernel addresses memory through buffer descriptors with 32-bit offsets; the BIG variant moves
+// the descriptor's 64-bit base instead of growing the offset -- to the chunk's 8 input planes for
+// the loads, to the output channel for everything the epilogue touches -- so that every offset
+// stays inside a few planes (8 planes must stay under 2 GiB: tiles up to 8192 x 8192).  Same
+// arithmetic in the same order: results are bit-identical to the plain variant's.
+template <int EPI, int TXW, bool BIG = false>
 __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     constexpr int TYW = Geo<TXW>::TYW, PR = Geo<TXW>::PR, PC = Geo<TXW>::PC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -114,8 +120,15 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int HW = a.H * a.W;
 
     constexpr unsigned kOob = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, BIG ? 0 : a.x_bytes, 0x00020000);
+    // BIG: the 8 input planes of one chunk (fewer in the last one; what lies behind reads as zero)
+    auto x_rebase = [&](int chunk) __attribute__((always_inline)) {
+        const int k0 = sgpr(chunk * KC);
+        const int nk = a.K - k0 < KC ? a.K - k0 : KC;
+        rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + (size_t)k0 * (size_t)HW, 0,
+                                               (nk > 0 ? nk : 0) * HW * 4, 0x00020000);
+    };
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
 
@@ -229,7 +242,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     };
     auto load_stage = [&](int chunk) {
         const unsigned ws = (unsigned)sgpr((int)(w_base + (unsigned)chunk * w_chunk));
-        const unsigned xs = (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
+        const unsigned xs = BIG ? 0u : (unsigned)sgpr((int)((unsigned)chunk * x_chunk));
+        if (BIG) x_rebase(chunk);
 #pragma unroll
         for (int n = 0; n < 4; ++n) u_load(n, ws);
 #pragma unroll
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         unsigned ws = 0, xs = 0;
         if (LOAD) {
             ws = (unsigned)sgpr((int)(w_base + (unsigned)(chunk + 2) * w_chunk));
-            xs = (unsigned)sgpr((int)((unsigned)(chunk + 2) * x_chunk));
+            xs = BIG ? 0u : (unsigned)sgpr((int)((unsigned)(chunk + 2) * x_chunk));
+            if (BIG) x_rebase(chunk + 2);
         }
         const float *next = lds + (cur ^ 1) * STAGE;
 #pragma unroll
@@ -429,15 +444,24 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                                                            : kOob;
     }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
+        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, BIG ? 0 : (int)plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.mask), 0, a.mask ? (int)plane_bytes : 0, 0x00020000);
+        const_cast<float *>(a.mask), 0, a.mask && !BIG ? (int)plane_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad ? (int)plane_bytes : 0, 0x00020000);
+        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad && !BIG ? (int)plane_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rft = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
+        const_cast<float *>(a.inj.feat), 0, a.inj.feat && !BIG ? (int)plane_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    // BIG: a descriptor on channel c of an [M][H][W] array -- the lane's own channel is c or c + 4
+    // (its half), so five planes are in reach; what lies past channel M - 1 is out of range
+    auto at_channel = [&](const float *base, const __amdgpu_buffer_rsrc_t &whole, int c)
+                          __attribute__((always_inline)) {
+        if (!BIG) return whole;
+        const int left = a.M - c < 5 ? a.M - c : 5;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base) + (size_t)c * (size_t)HW, 0,
+                                                 base && left > 0 ? left * HW * 4 : 0, 0x00020000);
+    };
     const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
         a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
@@ -463,13 +487,14 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
         return v;
     };
-    auto st2 = [&](int y, unsigned so, f32x2 v, auto even_c) __attribute__((always_inline)) {
+    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
+                   __attribute__((always_inline)) {
         if (decltype(even_c)::value) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), ry, vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
         } else {
             const float v0 = v.x, v1 = v.y;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, vo[y][0], so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ry, vo[y][1], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, vo[y][1], so, 0);
         }
     };
     // The ReLU mask and the style term, for all sixteen outputs of the lane (see kEarly above).
@@ -487,10 +512,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         auto prefetch = [&](auto even_c) __attribute__((always_inline)) {
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const unsigned so = (unsigned)chan(n >> 3, (n >> 1) & 3) * HW4;
-                if (a.mask) mk[n] = ld2(rmask, n & 1, so, even_c);
+                const int c = chan(n >> 3, (n >> 1) & 3);
+                const unsigned so = BIG ? 0u : (unsigned)c * HW4;
+                if (a.mask) mk[n] = ld2(at_channel(a.mask, rmask, c), n & 1, so, even_c);
                 if (EPI == kEpiDgradInject) {
-                    if (a.inj.sgrad) sg[n] = ld2(rsg, n & 1, so, even_c);
+                    if (a.inj.sgrad) sg[n] = ld2(at_channel(a.inj.sgrad, rsg, c), n & 1, so, even_c);
                 }
             }
         };
@@ -579,7 +605,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {           // the two channels of the register pair
                     const int rr = 2 * qq + h, c = chan(i, rr);
-                    const unsigned so = (unsigned)c * HW4;
+                    const unsigned so = BIG ? 0u : (unsigned)c * HW4;
+                    const __amdgpu_buffer_rsrc_t ry_c = at_channel(a.y, ry, c);
                     f32x2 o[2];
 #pragma unroll
                     for (int y = 0; y < 2; ++y) {
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                                 if (content) {
                                     // (one layer per tile evaluation takes this: the content map
                                     // is read where it is used, not ahead of time)
-                                    const f32x2 ft = ld2(rft, y, so, even_c);
+                                    const f32x2 ft = ld2(at_channel(a.inj.feat, rft, c), y, so, even_c);
                                     const int mm = c + 4 * half;
                                     const int cm = mm < a.M ? mm : 0;     // (lanes past M store nothing)
                                     const float *cp = content + (size_t)cm * cw_ch * cw_cw + crow[y];
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             }
                         }
                         o[y] = v;
-                        st2(y, so, v, even_c);
+                        st2(ry_c, y, so, v, even_c);
                     }
                     // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
                     // that follows (ceil mode: the second row may be missing): pool.hip's
@@ -766,9 +793,9 @@ bool wino2_fuses_pool(const ConvProblem &p) {
            (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
-template <int EPI, int TXW>
+template <int EPI, int TXW, bool BIG = false>
 static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_wino2_kernel<EPI, TXW>;
+    auto kern = conv_wino2_kernel<EPI, TXW, BIG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
@@ -806,16 +833,23 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     const double xb = 4.0 * p.K * (double)p.H * p.W;
     const double wb = 4.0 * (double)wino2_packed_floats(p.K, p.M);
     const double yb = 4.0 * p.M * (double)p.H * p.W;       // the epilogue addresses the output planes
-    if (xb >= 2147483648.0 || wb >= 2147483648.0 || yb >= 2147483648.0) {   // through descriptors too
-        set_error("wino2_launch: plane set exceeds the 2 GiB buffer-addressing limit");
+    // through descriptors too.  2 GiB and more: the BIG variant, which re-bases its descriptors per
+    // chunk / per channel and needs 8 planes (and the pooled output, if fused) under 2 GiB.
+    // STX_WINO_BIG=1 forces it on every plane (tests: results must not change).
+    const char *force_big = getenv("STX_WINO_BIG");
+    const bool huge = xb >= 2147483648.0 || yb >= 2147483648.0;
+    if (wb >= 2147483648.0 || 32.0 * (double)p.H * p.W >= 2147483648.0) {
+        set_error("wino2_launch: a %d x %d plane is beyond the buffer-addressing limit", p.H, p.W);
         return STX_ERR_UNSUPPORTED;
     }
-    a.x_bytes = (int)xb;
     a.w_bytes = (int)wb;
     const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
     int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
-    const bool split = ksplit > 1 && p.splitk_ws &&
+    // (planes that large never need a K split; the slices' kernel has no BIG form)
+    const bool split = ksplit > 1 && p.splitk_ws && !huge &&
                        p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
+    const bool big = huge || (force_big && atoi(force_big) == 1 && !split);
+    a.x_bytes = big ? 0 : (int)xb;
     if (split) {
         a.ksplit = ksplit;
         a.y = p.splitk_ws;
@@ -827,8 +861,12 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
 #define STX_W2_CASE(E)                                                                            \
     case E:                                                                                       \
-        STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8>(s, a, n_wg))                              \
-                              : (wino2_launch_epi<E, 32>(s, a, n_wg)));                           \
+        if (big && E != kEpiPartial)                                                              \
+            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8, true>(s, a, n_wg))                    \
+                                  : (wino2_launch_epi<E, 32, true>(s, a, n_wg)));                 \
+        else                                                                                      \
+            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8>(s, a, n_wg))                          \
+                                  : (wino2_launch_epi<E, 32>(s, a, n_wg)));                       \
         break;
     switch (epi) {
         STX_W2_CASE(kEpiForward)

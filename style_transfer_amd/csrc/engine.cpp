@@ -428,6 +428,11 @@ static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, Co
         *out = wino_config_by_id(1);
         return true;
     }
+    // plane sets of 2 GiB and more: only the eight-wave kernel has the re-based addressing
+    if (4.0 * std::max(K, M) * (double)H * W >= 2147483648.0) {
+        *out = wino2_config(wino2_pick_geometry(H, W));
+        return true;
+    }
     // Two kernels with identical arithmetic (bit-identical results).  The eight-wave one is a
     // percent or two faster where both offer the same patch geometry and has the registers to
     // request everything a loss-injecting epilogue reads at once (the four-wave one spills

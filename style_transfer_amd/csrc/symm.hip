@@ -45,6 +45,9 @@ size_t symm_pieces_elems(int C) {
     return 3 * cp * cp;
 }
 
+// BIG: F / S of 2 GiB and more -- the descriptors are moved to the step's 16 channels (loads) and
+// to the output row (stores) instead of reaching them through the 32-bit offset.
+template <bool BIG>
 __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restrict__ F,
                                                           const unsigned short *__restrict__ Dp,
                                                           float *__restrict__ S,
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
 
     constexpr unsigned kOob = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rf =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, f_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(S, 0, f_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, BIG ? 0 : f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(S, 0, BIG ? 0 : f_bytes, 0x00020000);
     // per-lane byte offsets of the two pixel blocks (k group g starts 8 rows further down)
     unsigned voff[2];
 #pragma unroll
@@ -103,12 +106,18 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
         // (a scalar offset must not exceed the descriptor's range: channels past C are clamped to
         // C, where every lane is out of range and reads zero)
         const int k0 = __builtin_amdgcn_readfirstlane(step * 16);
+        const int left = C - k0 < 16 ? C - k0 : 16;
+        const __amdgpu_buffer_rsrc_t rk =
+            BIG ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F) + (size_t)k0 * (size_t)HW, 0,
+                                                    (left > 0 ? left : 0) * HW * 4, 0x00020000)
+                : rf;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 raw[slot_][j][e] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rf, voff[j], (unsigned)min(k0 + e, C) * HW4, 0));
+                    float, __builtin_amdgcn_raw_buffer_load_b32(
+                               rk, voff[j], BIG ? (unsigned)e * HW4 : (unsigned)min(k0 + e, C) * HW4, 0));
     };
 
     f32x16b acc[2][2];
@@ -170,7 +179,13 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const unsigned so = (unsigned)min(__builtin_amdgcn_readfirstlane(m0 + i * 32 + (r & 3) + 8 * (r >> 2)), C) * HW4;
+            const int row0 = min(__builtin_amdgcn_readfirstlane(m0 + i * 32 + (r & 3) + 8 * (r >> 2)), C);
+            const unsigned so = BIG ? 0u : (unsigned)row0 * HW4;
+            const int rows_left = C - row0 < 5 ? C - row0 : 5;
+            const __amdgpu_buffer_rsrc_t rrow =
+                BIG ? __builtin_amdgcn_make_buffer_rsrc(S + (size_t)row0 * (size_t)HW, 0,
+                                                        (rows_left > 0 ? rows_left : 0) * HW * 4, 0x00020000)
+                    : rs;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int px = px0 + j * 32 + l31;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
                 const float v = acc[i][j][r];
                 asum += ok ? fabsf(v) : 0.f;
                 const unsigned vo = ok ? (unsigned)((4 * g) * HW + px) * 4u : kOob;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rrow, vo, so, 0);
             }
         }
 #pragma unroll
@@ -206,8 +221,9 @@ int symm_num_workgroups(int C, int HW) { return ceil_div(C, kSM) * ceil_div(HW, 
 bool symm_bf3_usable(const float *feat, const float *out, int C, int HW) {
     const char *env = getenv("STX_SYMM");
     if (env && !strcmp(env, "fp32")) return false;
-    const double bytes = 4.0 * C * (double)HW;
-    return bytes < 2147483648.0 && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
+    // (16 planes must stay under 2 GiB: the reach of one step's loads in the BIG variant)
+    return 64.0 * (double)HW < 2147483648.0 &&
+           ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
 }
 
 int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
@@ -218,8 +234,14 @@ int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigne
         STX_CHECK_LAUNCH();
     }
     const int m_tiles = Cp / kSM;
-    symm_bf3_kernel<<<symm_num_workgroups(C, HW), 256, 0, s>>>(
-        feat, pieces, out, partials, C, Cp, HW, (unsigned)(4.0 * C * (double)HW), m_tiles);
+    const double bytes = 4.0 * C * (double)HW;
+    const char *force_big = getenv("STX_WINO_BIG");
+    if (bytes >= 2147483648.0 || (force_big && atoi(force_big) == 1))
+        symm_bf3_kernel<true><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, pieces, out, partials, C, Cp,
+                                                                       HW, 0u, m_tiles);
+    else
+        symm_bf3_kernel<false><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, pieces, out, partials, C, Cp,
+                                                                        HW, (unsigned)bytes, m_tiles);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
