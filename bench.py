@@ -232,38 +232,52 @@ def whole_run_wall_clock(devices):
             'wall_clock_summary': summary}
 
 
+# Gram + SYMM of the five default style layers of VGG-19: each product is 2 * C * C * h * w FLOP and
+# C * C * h * w = 2^32 / 2^20 per tile pixel for conv1_1 .. conv4_1 (a quarter of that for conv5_1)
+GRAM_SYMM_FLOP_PER_TILE_PIXEL = int(2 * 2 * 4096 * (4 + 0.25))
+BF16X3_PIPE_TIME = 6 * 32 / (8 * 64)    # six bf16 MFMAs (32 cycles) per 16 k instead of eight fp32 ones (64)
+
+
 def roofline_record(eng, avg_group_ms):
-    """Matrix-core work issued by one GPU's four concurrent tile evaluations over their HIP-event
-    span, against the fp32 MFMA peak."""
+    """Matrix-pipe work of one GPU's four concurrent tile evaluations over their HIP-event span,
+    against the fp32 MFMA peak.  Every term is the time the kernels' own instructions need on the
+    matrix pipe, expressed in fp32-MFMA FLOP: Winograd convolutions issue 4/9 (2-D) or 2/3 (1-D) of
+    a direct convolution's fp32 MFMAs; Gram and SYMM issue six bf16 MFMAs per 16 k, which occupy
+    the pipe for 0.375 of the time their fp32 form would -- so frac <= 1 by construction."""
     flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
     direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
-    # what the kernels actually put on the matrix cores: the 3x3 layers run Winograd kernels
-    # that issue 4/9 (2-D) or 2/3 (1-D) of the direct-convolution MFMAs; Gram / SYMM in full
     conv_alg, conv_issued = eng.last_tile_flops()
-    issued = (flop / TILES_PER_GPU - conv_alg + conv_issued) * TILES_PER_GPU
+    terms = GRAM_SYMM_FLOP_PER_TILE_PIXEL * TILE * TILE
+    bf16_terms = os.environ.get('STX_GRAM') != 'fp32' and os.environ.get('STX_SYMM') != 'fp32'
+    per_tile = flop / TILES_PER_GPU - conv_alg - terms + conv_issued
+    issued_r02 = (per_tile + terms) * TILES_PER_GPU            # round-2 accounting: terms at the fp32 rate
+    issued = (per_tile + terms * (BF16X3_PIPE_TIME if bf16_terms else 1.0)) * TILES_PER_GPU
     issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
     bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
     traffic, traffic_src = measured_traffic()
     return {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
+            'frac_round2_accounting': issued_r02 / (avg_group_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / TILES_PER_GPU,
             'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
             'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_wino2_kernel<0|1|3,32> '
-                      '(3x3 layers forward / backward / loss-injecting backward; dominant), '
-                      'conv_mfma_kernel (first layer, SYMM), conv3x3_m4_kernel (backward into the '
-                      'image), gram_partial_* / gram_finish_kernel' % TILES_PER_GPU,
+                      '(3x3 layers forward / backward / loss-injecting backward; 80 %% of the time), '
+                      'conv_mfma_kernel (first layer), conv3x3_m4_kernel (backward into the image), '
+                      'gram_partial_bf3_kernel / symm_bf3_kernel (bf16 MFMA, three-piece split)'
+                      % TILES_PER_GPU,
             'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
             'achieved_direct_equiv': direct_equiv,
             'flop_direct_equiv_per_launch': flop,
-            'note': 'achieved / frac = matrix-core FLOP actually issued (Winograd '
-                    'F(2x2,3x3) convolutions issue 4/9 of a direct convolution, Gram '
-                    'and SYMM in full) over the HIP-event time of the launch group, '
-                    'against the fp32 MFMA peak at 2.4 GHz; achieved_direct_equiv '
-                    'credits every convolution as a direct one (SURVEY 8d: 1 514 240 '
-                    'FLOP per tile pixel) and is not a roofline fraction; traffic is '
-                    'a replay of the committed PMC profile named in traffic_source, '
-                    'not a measurement of this run'}
+            'note': 'achieved / frac = matrix-pipe work actually issued, in fp32-MFMA FLOP (Winograd '
+                    'F(2x2,3x3) convolutions issue 4/9 of a direct convolution; Gram and SYMM run as '
+                    'six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 form and are '
+                    'counted at that) over the HIP-event time of the launch group, against the fp32 '
+                    'MFMA peak at 2.4 GHz; frac_round2_accounting counts Gram and SYMM in full as '
+                    'round 2 did (they ran on the fp32 pipe then); achieved_direct_equiv credits '
+                    'every convolution as a direct one (SURVEY 8d: 1 514 240 FLOP per tile pixel) '
+                    'and is not a roofline fraction; traffic is a replay of the committed PMC '
+                    'profile named in traffic_source, not a measurement of this run'}
 
 
 def main():

@@ -113,6 +113,14 @@ struct ConvProblem {
     int epilogue;
     ConvInject inject;     // kEpiDgrad, optional
     unsigned char *pool_codes = nullptr;   // with pool_out: one window code per pooled element (pool.hip)
+    // ReLU sign nibbles of a [C][H][W] blob, one byte per 2x2 window ([C][ceil(H/2)][ceil(W/2)],
+    // bit 2*dy+dx = element (2y+dy, 2x+dx) > 0).  kEpiForward: in_codes (optional) receives the
+    // nibbles of the INPUT planes x -- the forward pass of the layer that consumes a rectified blob
+    // writes them as a by-product of staging its patches; kEpiDgrad: mask_codes (optional) replaces
+    // the fp32 `mask` array, 1 byte instead of 16 per lane and channel.  Kernels that cannot use
+    // them ignore them (conv_uses_relu_codes).
+    unsigned char *in_codes = nullptr;
+    const unsigned char *mask_codes = nullptr;
     float *pool_out = nullptr;       // kEpiForward: also write the 2x2/2 ceil-mode pooling of y here
     int pool_mode = 0;               // (kernels that cannot do it leave it to the caller: see
                                      // wino2_fuses_pool)
@@ -164,6 +172,8 @@ struct WinoArgs {
     float *pool_out;       // forward only: 2x2/2 pooling of the output, or null
     int pool_mode;
     unsigned char *pool_codes;   // with pool_out: window codes for the backward pass, or null
+    unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
+    const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
 };
 
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
@@ -183,6 +193,8 @@ int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int 
                        float *packed);
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 bool wino2_fuses_pool(const ConvProblem &p);
+// True if a launch of p under cfg writes p.in_codes (forward) / reads p.mask_codes (backward).
+bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 
 // Four-wave form of the same kernel (conv_wino4.hip); config ids 210 (4 x 64 pixel patches),

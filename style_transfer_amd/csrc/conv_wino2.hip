@@ -83,7 +83,12 @@ __device__ __forceinline__ void lds_barrier() {
 // the loads, to the output channel for everything the epilogue touches -- so that every offset
 // stays inside a few planes (8 planes must stay under 2 GiB: tiles up to 8192 x 8192).  Same
 // arithmetic in the same order: results are bit-identical to the plain variant's.
-template <int EPI, int TXW, bool BIG = false>
+// MK: ReLU sign nibbles (ConvProblem::in_codes / mask_codes).  Forward: the kernel writes those of
+// its input; backward: the mask comes as nibbles (one byte per lane and channel) instead of the
+// fp32 blob.  (A template parameter, not a run-time test: the forward kernels that do not emit --
+// the 512-channel layers, whose backward pass is matrix-bound and gains nothing -- were 1 % slower
+// with the untaken branch in their main loop.)
+template <int EPI, int TXW, bool BIG = false, bool MK = false>
 __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     constexpr int TYW = Geo<TXW>::TYW, PR = Geo<TXW>::PR, PC = Geo<TXW>::PC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,6 +162,22 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                            ? (unsigned)(off < 0 ? 0 : off) * 4u : kOob;
         }
     }
+    // ReLU sign nibbles of the INPUT (forward, first channel tile only): this thread's patch holds
+    // the 2x2 window at rows 2ty, 2ty+1 / columns 2tx, 2tx+1 in its middle -- patch rows 1, 2,
+    // columns 1, 2 -- so the layer that consumes a rectified blob leaves, for the price of ten
+    // vector instructions per chunk, what its own backward pass needs of that blob: one byte per
+    // window instead of 16 bytes of fp32 mask per lane and channel (conv1_2's backward fetched
+    // 908 MB, 268 of them conv1_1 read only for its signs).
+    const int cph = (a.H + 1) >> 1, cpw = (a.W + 1) >> 1;
+    const bool emit = EPI == kEpiForward && MK && mtile == 0;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        a.in_codes, 0, emit ? a.K * cph * cpw : 0, 0x00020000);
+    unsigned cvoff = kOob;
+    {
+        const int ty = lane / TXW, tx = lane % TXW;
+        if (y0 + 2 * ty < a.H && x0 + 2 * tx < a.W)
+            cvoff = (unsigned)(wave * cph * cpw + ((y0 >> 1) + ty) * cpw + (x0 >> 1) + tx);
+    }
     const bool edge_l = x0 == 0, edge_r = x0 + PC + 2 > a.W;      // workgroup-uniform
     const bool ok2 = st_x + 2 < a.W, ok3 = st_x + 3 < a.W;
     const unsigned w_base = (unsigned)(mtile * a.w_tile_stride) * 4u;
@@ -214,6 +235,19 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             }
         }
     };
+    auto emit_codes = [&](int chunk) {     // (after fix_edges: what lies outside the plane is zero)
+        // x > 0 for a float is bits > 0 for its pattern read as a signed integer (-0.0 and the
+        // negatives are negative integers): clamp(bits, 0, 1) is one v_med3_i32 per element,
+        // seven vector instructions per nibble -- they are not hidden behind the fp32 MFMAs
+        auto pos = [](float v) __attribute__((always_inline)) {
+            const int b = __builtin_bit_cast(int, v);
+            return (unsigned)min(max(b, 0), 1);
+        };
+        const unsigned nib = pos(xreg[1].y) | (pos(xreg[1].z) << 1) | (pos(xreg[2].y) << 2) |
+                             (pos(xreg[2].z) << 3);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rin, cvoff,
+                                             (unsigned)sgpr(chunk * KC * cph * cpw), 0);
+    };
     // rows: t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3 on column pair h
     auto row_op = [&](int q) {
         const int h = q >> 2, which = q & 3;
@@ -254,6 +288,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) u_write(n, ldsb);
         fix_edges();
+        if (emit) emit_codes(c_begin);
 #pragma unroll
         for (int q = 0; q < 8; ++q) row_op(q);
 #pragma unroll
@@ -325,7 +360,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                         // Bt d B as ONE burst of vector work: an isolated vector instruction
                         // between two MFMAs costs the matrix pipe ~13 cycles, the members of a
                         // burst ~4 each (tools/ubench/solo_issue.hip)
-                        if (p == 8) fix_edges();
+                        if (p == 8) {
+                            fix_edges();
+                            if (emit) emit_codes(chunk + 1);
+                        }
                         if (p == 9) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) row_op(q);
@@ -453,6 +491,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         const_cast<float *>(a.inj.feat), 0, a.inj.feat && !BIG ? (int)plane_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(a.mask_codes), 0, MK ? a.M * cph * cpw : 0, 0x00020000);
+    const unsigned vmc = (yy < a.H && xx0 < a.W)
+                             ? (unsigned)((4 * half) * cph * cpw + (yy >> 1) * cpw + (xx0 >> 1))
+                             : kOob;
     // BIG: a descriptor on channel c of an [M][H][W] array -- the lane's own channel is c or c + 4
     // (its half), so five planes are in reach; what lies past channel M - 1 is out of range
     auto at_channel = [&](const float *base, const __amdgpu_buffer_rsrc_t &whole, int c)
@@ -498,7 +541,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         }
     };
     // The ReLU mask and the style term, for all sixteen outputs of the lane (see kEarly above).
-    f32x2 mk[16], sg[16];
+    f32x2 mk[MK ? 1 : 16], sg[16];
+    unsigned mkb[MK ? 8 : 1];      // MK: the 2x2 window's sign nibble per channel
     float bs[8];
     if (EPI == kEpiForward) {
         if (a.bias) {
@@ -514,7 +558,12 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
             for (int n = 0; n < 16; ++n) {
                 const int c = chan(n >> 3, (n >> 1) & 3);
                 const unsigned so = BIG ? 0u : (unsigned)c * HW4;
-                if (a.mask) mk[n] = ld2(at_channel(a.mask, rmask, c), n & 1, so, even_c);
+                if (MK) {
+                    if ((n & 1) == 0)
+                        mkb[n >> 1] = __builtin_amdgcn_raw_buffer_load_b8(rmc, vmc, (unsigned)(c * cph * cpw), 0);
+                } else if (a.mask) {
+                    mk[n] = ld2(at_channel(a.mask, rmask, c), n & 1, so, even_c);
+                }
                 if (EPI == kEpiDgradInject) {
                     if (a.inj.sgrad) sg[n] = ld2(at_channel(a.inj.sgrad, rsg, c), n & 1, so, even_c);
                 }
@@ -615,7 +664,11 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                         if (EPI == kEpiForward) {
                             if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
                         } else if (EPI != kEpiPartial) {
-                            if (a.mask) {
+                            if (MK) {
+                                const unsigned nib = mkb[n >> 1] >> (2 * y);
+                                v.x = (nib & 1u) ? v.x : 0.f;
+                                v.y = (nib & 2u) ? v.y : 0.f;
+                            } else if (a.mask) {
                                 v.x = mk[n].x > 0.f ? v.x : 0.f;
                                 v.y = mk[n].y > 0.f ? v.y : 0.f;
                             }
@@ -787,15 +840,29 @@ int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int 
     return STX_OK;
 }
 
+// The eight-wave kernel writes / reads ReLU sign nibbles unless the launch is sliced along K.
+// STX_RELU_CODES=0 (read at every call) keeps the fp32 masks, for A/B measurements and tests.
+bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    const char *env = getenv("STX_RELU_CODES");
+    if (env && atoi(env) == 0) return false;
+    if (cfg.id < 200 || cfg.id >= 210 || ksplit > 1) return false;
+    const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
+    if (xb >= 2147483648.0 || yb >= 2147483648.0) return false;
+    const char *force_big = getenv("STX_WINO_BIG");
+    if (force_big && atoi(force_big) == 1) return false;
+    return p.epilogue == kEpiForward ? p.in_codes != nullptr
+                                     : p.epilogue == kEpiDgrad && p.mask_codes != nullptr;
+}
+
 // The forward epilogue pools only on its float2 path (even rows, 8-byte aligned arrays).
 bool wino2_fuses_pool(const ConvProblem &p) {
     return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
            (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
-template <int EPI, int TXW, bool BIG = false>
+template <int EPI, int TXW, bool BIG = false, bool MK = false>
 static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_wino2_kernel<EPI, TXW, BIG>;
+    auto kern = conv_wino2_kernel<EPI, TXW, BIG, MK>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
@@ -850,6 +917,12 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
                        p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
     const bool big = huge || (force_big && atoi(force_big) == 1 && !split);
     a.x_bytes = big ? 0 : (int)xb;
+    // ReLU sign nibbles (see ConvProblem): written by the plain forward kernel, read by the plain
+    // backward kernels; K slices and the BIG variants keep the fp32 mask
+    const bool codes = conv_uses_relu_codes(cfg, p, split ? ksplit : 1) && !big;
+    a.in_codes = codes && p.epilogue == kEpiForward ? p.in_codes : nullptr;
+    a.mask_codes = codes && p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
+    const bool mk = a.mask_codes != nullptr || a.in_codes != nullptr;
     if (split) {
         a.ksplit = ksplit;
         a.y = p.splitk_ws;
@@ -864,6 +937,9 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         if (big && E != kEpiPartial)                                                              \
             STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8, true>(s, a, n_wg))                    \
                                   : (wino2_launch_epi<E, 32, true>(s, a, n_wg)));                 \
+        else if (mk && (E == kEpiForward || E == kEpiDgrad || E == kEpiDgradInject))              \
+            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8, false, true>(s, a, n_wg))             \
+                                  : (wino2_launch_epi<E, 32, false, true>(s, a, n_wg)));          \
         else                                                                                      \
             STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8>(s, a, n_wg))                          \
                                   : (wino2_launch_epi<E, 32>(s, a, n_wg)));                       \

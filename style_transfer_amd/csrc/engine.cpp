@@ -87,6 +87,8 @@ struct Blob {
     DevBuf data, diff;
     DevBuf codes;             // pooled blobs: one window code per element (pool.hip), written by the
     bool codes_valid = false; // forward pass that produced `data` if its kernel can
+    DevBuf relu_codes;        // rectified blobs: sign nibbles per 2x2 window (ConvProblem::in_codes),
+    bool relu_codes_valid = false;   // written by the forward pass of the convolution that reads the blob
     size_t count() const { return (size_t)channels * h * w; }
 };
 
@@ -528,9 +530,9 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
 // the caller whether the convolution wrote its output too.
 int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool = nullptr,
-                     bool *pooled = nullptr) {
+                     bool *pooled = nullptr, bool relu_codes = false) {
     const Layer &L = e->layers[li];
-    const Blob &b = e->blobs[L.bottom_blob];
+    Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
     const ConvParams &cp = e->sh->conv[li];
     ConvProblem p{};
@@ -550,6 +552,19 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
+    // a backward pass will follow: let this layer leave the sign nibbles of its (rectified) input
+    // (up to 128 input channels -- conv1_2 and conv2_2 of a VGG: their backward pass is co-limited
+    // by HBM and gains 40 / 24 us from the byte masks on a 1024^2 tile, while emitting them costs
+    // the forward pass 10 / 16 us; from 256 channels on the backward pass is matrix-bound, gains
+    // 0-7 us and the forward pass pays 5-10: measured, profiles/r03_relu_codes_ab.txt)
+    b.relu_codes_valid = false;
+    if (relu_codes && b.relu && b.channels <= 128) {
+        const size_t bytes = (size_t)b.channels * ((b.h + 1) / 2) * ((b.w + 1) / 2);
+        STX_TRY(b.relu_codes.ensure(bytes));
+        p.in_codes = static_cast<unsigned char *>(b.relu_codes.ptr);
+        b.relu_codes_valid = conv_uses_relu_codes(cfg, p, conv_splitk_factor(cfg, p, true));
+        if (!b.relu_codes_valid) p.in_codes = nullptr;
+    }
     if (pooled) *pooled = false;
     if (pool) {
         Blob &pt = e->blobs[pool->top_blob];
@@ -580,6 +595,8 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     p.x = t.diff.f();
     p.y = b.diff.f();
     p.mask = b.relu ? b.data.f() : nullptr;
+    // (kernels that cannot read the nibbles use the fp32 blob: conv_uses_relu_codes)
+    p.mask_codes = b.relu && b.relu_codes_valid ? static_cast<const unsigned char *>(b.relu_codes.ptr) : nullptr;
     p.K = cp.cout;
     p.M = cp.cin;
     p.H = b.h;
@@ -622,7 +639,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
 // even when no ReLU layer follows it (np.maximum(0, .) at style_transfer.py:426,567).
 // `after_blob` (optional) is called as soon as a blob is complete, before the next layer is queued.
 int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
-            const std::function<int(int)> *after_blob = nullptr) {
+            const std::function<int(int)> *after_blob = nullptr, bool relu_codes = false) {
     int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
@@ -645,7 +662,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
                 }
             }
             bool pooled = false;
-            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled));
+            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled, relu_codes));
             if (pooled) pooled_layer = pool_li;
             if (after_blob) {
                 STX_TRY((*after_blob)(L.top_blob));
@@ -993,6 +1010,7 @@ void stx_engine_destroy(stx_engine *e) {
         b.data.release();
         b.diff.release();
         b.codes.release();
+        b.relu_codes.release();
     }
     e->graphs.clear();
     for (hipEvent_t ev : e->fence_events) (void)hipEventDestroy(ev);
@@ -1477,7 +1495,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     };
     if (!g) STX_TRY(begin_timing(e));
     e->flop_algorithmic = e->flop_issued = 0;
-    STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr));
+    STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true));
     if (!interleave) {
         STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
         STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
