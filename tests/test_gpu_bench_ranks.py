@@ -50,3 +50,31 @@ def test_two_rank_bench_matches_single_process_loss():
     b = _line(one.stdout)
     assert b['config']['tiles_per_step'] == 8
     assert a['config']['final_loss'] == pytest.approx(b['config']['final_loss'], rel=1e-6)
+
+
+def test_farm_leg_over_two_device_entries_matches_one():
+    """bench.py's `farm` sub-record (north_star's layout: one host process, TileFarm over the
+    job's GPUs) on a one-GPU box: the device list [0, 0] gives two groups of four engines on GPU 0,
+    eight tiles per step.  Same tiles, same arithmetic: the loss after two steps equals the
+    single-entry farm's bit for bit, and the second device entry shares the first one's weights
+    and targets (one copy per GPU)."""
+    sys.path.insert(0, REPO)
+    import bench
+    from style_transfer_amd import lib
+    from style_transfer_amd.netspec import builtin_net
+    from style_transfer_amd.weights import synthetic_weights
+    if lib.device_count() < 1:
+        pytest.fail('no GPU visible')
+    net = builtin_net('vgg19')
+    weights = synthetic_weights(net, 0)
+    losses = []
+    for devices in ([0], [0, 0]):
+        job = bench.FarmJob(net, weights, devices, 2, 4)
+        _, loss = job.timed(2, 1)
+        assert job.farm.tile_evals == 3 * 8 and len(job.group_ms) == 2
+        if len(devices) == 2:
+            assert len(job.farm.engines) == 8 and len(job.farm.primaries()) == 1
+            assert job.eng.query(lib.Q_SHARED_ENGINES) == 8
+        losses.append(loss)
+        job.close()
+    assert losses[0] == losses[1]
