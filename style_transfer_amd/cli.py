@@ -111,18 +111,23 @@ def main(argv=None):
         for layer, shape in net.shapes().items():
             print('% 25s %s' % (layer, shape))
         return 0
+    # The weight file is read (or the seeded bank drawn) on a helper thread while this one wakes
+    # the GPU runtime up and decodes the pictures: all three release the interpreter lock.
+    loader = ThreadPoolExecutor(max_workers=1)
+    weights_future = loader.submit(load_weights, args.weights, net)
     n_gpus = lib.device_count()
     if n_gpus < 1:
         raise RuntimeError('no AMD GPU visible: this engine has no CPU path')
     devices = [d if d >= 0 else 0 for d in args.devices]
     print('Initializing %s on device(s) %s.' % (args.weights, devices))
-    weights = load_weights(args.weights, net)
-    farm = TileFarm(net, devices, weights)
-    transfer = StyleTransfer(farm, args, state)
     content_image = Image.open(args.content_image).convert('RGB')
     style_images = [Image.open(p).convert('RGB') for p in args.style_images]
     initial_image = Image.open(args.init_image).convert('RGB') if args.init_image else None
     aux_image = Image.open(args.aux_image).convert('RGB') if args.aux_image else None
+    weights = weights_future.result()
+    loader.shutdown()
+    farm = TileFarm(net, devices, weights)
+    transfer = StyleTransfer(farm, args, state)
     stats = StatLogger()
     progress = Progress(run, stats, args.save_every)
     np.random.seed(args.seed)
