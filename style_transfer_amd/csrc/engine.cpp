@@ -205,8 +205,13 @@ struct stx_engine {
     float *arena_dev = nullptr;
     size_t arena_cap = 0, *arena_used = nullptr;
     // recorded tile evaluations (STX_GRAPH=0 turns them off), keyed by everything a recording bakes in
+    // A recording costs ~12 ms (capture + instantiate) and saves ~45 us of a 4-stream step per
+    // replay, nothing at the single-tile scales: it pays for itself after
+    // ~270 replays, so a key is recorded only once it has been evaluated that often kernel by
+    // kernel -- a pyramid level of 100-200 iterations never is (13 recordings made a whole
+    // `--size 2048` run 0.15 s SLOWER).  STX_GRAPH_MIN_EAGER=2 records at the third evaluation.
     bool graphs_on = true;
-    int graph_min_eager = 2;
+    int graph_min_eager = 300;
     TileGraph *recording = nullptr;
     std::map<std::string, std::unique_ptr<TileGraph>> graphs;
     size_t n_captures = 0, n_replays = 0, n_eager = 0;

@@ -18,8 +18,13 @@ from style_transfer_amd.weights import synthetic_weights
 pytestmark = pytest.mark.gpu
 
 
-def test_transfer_multiscale_matches_reference_run(golden):
+@pytest.mark.parametrize('recorded', [False, True])
+def test_transfer_multiscale_matches_reference_run(golden, recorded, monkeypatch):
+    """recorded: launch graphs from the second evaluation of a key on (default: after 300), so
+    that the third step of the first scale is a replay -- the reference's numbers must not move."""
     from argparse import Namespace
+    if recorded:
+        monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '1')
     argv = str(golden['e2e.argv']).split()
     state = Namespace()
     args = parse_args(state, argv, config_py=False)
@@ -45,6 +50,9 @@ def test_transfer_multiscale_matches_reference_run(golden):
     u8 = np.asarray(st.current_output)
     assert np.abs(u8.astype(int) - golden['e2e.final_u8'].astype(int)).max() <= 1
     assert farm.tile_evals == 4 * 3 + 4 * 2
+    from style_transfer_amd import lib
+    replays = sum(e.query(lib.Q_GRAPH_REPLAYS) for e in farm.engines)
+    assert (replays > 0) == recorded
     farm.close()
 
 

@@ -45,6 +45,7 @@ def test_replayed_graph_equals_eager_calls(model, monkeypatch):
         roll = (8 * rng.randint(-30, 30), 8 * rng.randint(-30, 30))
         calls.append((th, tw, start, roll, rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)))
     results = {}
+    monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')      # (default: 300 evaluations before a recording)
     for mode in ('0', '1'):
         monkeypatch.setenv('STX_GRAPH', mode)
         eng = TileEngine(net, 0, weights)
@@ -71,13 +72,14 @@ def test_replayed_graph_equals_eager_calls(model, monkeypatch):
         assert np.array_equal(ga, gb)
 
 
-def test_graph_instances_between_syncs_and_rerecording_after_new_targets():
+def test_graph_instances_between_syncs_and_rerecording_after_new_targets(monkeypatch):
     """Several evaluations of one key between two syncs each own their loss scalars (separate
     recordings), and new targets (a new scale: every device pointer may move) retire the old
     recordings instead of replaying them."""
     from style_transfer_amd import lib
     from style_transfer_amd.engine import TileEngine
     require_gpu()
+    monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')
     net = builtin_net('vgg19')
     eng = TileEngine(net, 0, synthetic_weights(net.as_dicts(), 0))
     rng = np.random.RandomState(2)
@@ -151,11 +153,12 @@ def test_engines_of_one_gpu_share_weights_banks_and_targets():
     farm.close()
 
 
-def test_lazy_loss_and_stream_ordered_gradient():
+def test_lazy_loss_and_stream_ordered_gradient(monkeypatch):
     """eval_sc_grad(lazy=True) returns without a host wait; the gradient is complete in stream
     order on the master and float(loss) equals the synchronous call."""
     from style_transfer_amd.farm import LazyLoss, TileFarm
     require_gpu()
+    monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')
     net = builtin_net('vgg19')
     weights = synthetic_weights(net.as_dicts(), 0)
     rng = np.random.RandomState(4)
