@@ -190,6 +190,40 @@ class FarmJob:
         self.farm.close()
 
 
+def farm_leg(devices, rows, cols, steps, warmup):
+    """The benchmark's step loop through TileFarm over `devices` in THIS process; the `farm`
+    sub-record."""
+    from style_transfer_amd.netspec import builtin_net
+    from style_transfer_amd.weights import synthetic_weights
+    net = builtin_net('vgg19')
+    job = FarmJob(net, synthetic_weights(net, 0), devices, rows, cols)
+    elapsed, loss = job.timed(steps, warmup)
+    record = {'layout': 'one host process, TileFarm over %d GPUs (xGMI peer copies, event-ordered, '
+                        'no host wait inside a step)' % len(devices),
+              'value': job.tiles_per_step * steps / elapsed, 'unit': 'tile-iterations/s',
+              'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'final_loss': loss,
+              'avg_launch_ms': float(np.mean(job.group_ms)), 'graphs': job.graph_counters()}
+    job.close()
+    return record
+
+
+def farm_leg_in_child(world, rows, cols, steps, warmup, timeout=300):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--farm-leg', str(world), '--debug-grid',
+           '%dx%d' % (rows, cols), '--steps', str(steps), '--warmup', str(warmup)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK')}
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              timeout=timeout)
+        rows_ = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+        if proc.returncode != 0 or not rows_:
+            return {'error': 'exit %d: %s' % (proc.returncode, proc.stderr.strip()[-400:])}
+        return json.loads(rows_[-1])
+    except Exception as err:      # pylint: disable=broad-except
+        return {'error': '%s: %s' % (type(err).__name__, err)}
+
+
 def whole_run_wall_clock(devices):
     """Wall-clock of the reference's command line for the metric's configuration, start to finish:
     `--size 2048 --tile-size 1024`, Adam, default iterations (200 + 6 x 100 over 7 scales = 1400
@@ -290,12 +324,19 @@ def main():
                     help='skip the whole-run wall-clock leg (about 10 s)')
     ap.add_argument('--no-farm-leg', action='store_true',
                     help='N > 1: skip the single-host-process (TileFarm) measurement')
+    ap.add_argument('--farm-leg', type=int, default=0, metavar='N',
+                    help='internal: only the single-host-process (TileFarm) step loop over GPUs 0..N-1 '
+                         'with the tile grid of --debug-grid; prints the `farm` sub-record')
     ap.add_argument('--steady-seconds', type=float, default=5.0)
     ap.add_argument('--debug-grid', default=None,
                     help='RxC tile grid instead of the one for --gpus (tests only: lets a single '
                          'process evaluate the image of a larger job)')
     opts = ap.parse_args()
 
+    if opts.farm_leg:
+        r, c = (int(v) for v in opts.debug_grid.split('x'))
+        print(json.dumps(farm_leg(list(range(opts.farm_leg)), r, c, opts.steps, opts.warmup)), flush=True)
+        return
     import torch                                       # first: one HIP runtime for both libraries
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -332,20 +373,10 @@ def main():
     devices = list(range(world)) if not debug_one_gpu else [0]
     if world > 1 and not opts.no_farm_leg and not debug_one_gpu:
         # north_star's layout on the same image and step loop: one host process, N GPUs.  The
-        # other ranks have left (their process group is gone, their engines are closed).
-        try:
-            job = FarmJob(net, synthetic_weights(net, 0), devices, rows, cols)
-            elapsed, loss = job.timed(opts.steps, opts.warmup)
-            line['farm'] = {'layout': 'one host process, TileFarm over %d GPUs (xGMI peer copies, '
-                                      'event-ordered, no host wait inside a step)' % world,
-                            'value': job.tiles_per_step * opts.steps / elapsed,
-                            'unit': 'tile-iterations/s', 'ms_per_step': elapsed / opts.steps * 1e3,
-                            'steps': opts.steps, 'final_loss': loss,
-                            'avg_launch_ms': float(np.mean(job.group_ms)),
-                            'graphs': job.graph_counters()}
-            job.close()
-        except Exception as err:      # pylint: disable=broad-except
-            line['farm'] = {'error': '%s: %s' % (type(err).__name__, err)}
+        # other ranks have left (their process group is gone, their engines are closed).  A child
+        # process with a deadline: a fault on a never-exercised peer path must not take the
+        # benchmark line with it.
+        line['farm'] = farm_leg_in_child(world, rows, cols, opts.steps, opts.warmup)
     if not opts.no_wall_clock and not debug_one_gpu:
         # the whole command-line run on this job's GPUs, one host process
         try:

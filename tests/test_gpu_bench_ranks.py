@@ -78,3 +78,14 @@ def test_farm_leg_over_two_device_entries_matches_one():
         losses.append(loss)
         job.close()
     assert losses[0] == losses[1]
+
+
+def test_farm_leg_child_process_prints_its_record():
+    """`bench.py --farm-leg N` (what rank 0 spawns for the `farm` sub-record at N > 1) on one GPU."""
+    proc = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--farm-leg', '1',
+                           '--debug-grid', '2x2', '--steps', '2', '--warmup', '1'], cwd=REPO,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    rec = _line(proc.stdout)
+    assert rec['unit'] == 'tile-iterations/s' and rec['value'] > 0 and rec['steps'] == 2
+    assert rec['graphs']['eager'] == 4 * 3
