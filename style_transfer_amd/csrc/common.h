@@ -121,6 +121,10 @@ struct ConvProblem {
     // them ignore them (conv_uses_relu_codes).
     unsigned char *in_codes = nullptr;
     const unsigned char *mask_codes = nullptr;
+    // kEpiForward with a fused pooling that also writes window codes: nobody will read y itself
+    // (the pooled blob feeds the next layer, the backward pooling runs from the codes) -- skip
+    // its stores.  Only honoured by the kernel that fuses (wino2_launch); ignored otherwise.
+    bool skip_y = false;
     float *pool_out = nullptr;       // kEpiForward: also write the 2x2/2 ceil-mode pooling of y here
     int pool_mode = 0;               // (kernels that cannot do it leave it to the caller: see
                                      // wino2_fuses_pool)
@@ -172,6 +176,7 @@ struct WinoArgs {
     float *pool_out;       // forward only: 2x2/2 pooling of the output, or null
     int pool_mode;
     unsigned char *pool_codes;   // with pool_out: window codes for the backward pass, or null
+    int skip_y = 0;                             // forward + fused pooling with codes: y is not stored
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
 };

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             }
                         }
                         o[y] = v;
-                        st2(ry_c, y, so, v, even_c);
+                        if (EPI != kEpiForward || !a.skip_y) st2(ry_c, y, so, v, even_c);
                     }
                     // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
                     // that follows (ceil mode: the second row may be missing): pool.hip's
@@ -930,6 +930,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     } else if (p.epilogue == kEpiForward && wino2_fuses_pool(p)) {
         a.pool_out = p.pool_out;
         a.pool_codes = p.pool_codes;
+        a.skip_y = p.skip_y && p.pool_codes != nullptr;
     }
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
 #define STX_W2_CASE(E)                                                                            \

@@ -535,7 +535,7 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
 // the caller whether the convolution wrote its output too.
 int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool = nullptr,
-                     bool *pooled = nullptr, bool relu_codes = false) {
+                     bool *pooled = nullptr, bool relu_codes = false, bool top_unobserved = false) {
     const Layer &L = e->layers[li];
     Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
@@ -582,6 +582,10 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
                 STX_TRY(pt.codes.ensure(pt.count()));
                 p.pool_codes = static_cast<unsigned char *>(pt.codes.ptr);
                 pt.codes_valid = true;
+                // the full-resolution blob is then dead weight unless somebody looks at it: the
+                // next layer reads the pooled blob, the backward pooling the codes (conv1_2 of a
+                // 1024^2 tile: 268 MB that were written and never read)
+                p.skip_y = top_unobserved;
             }
         } else {
             p.pool_out = nullptr;
@@ -643,8 +647,11 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
 // Runs the layers needed for `needed` blobs, in graph order.  `relu_blob` (or -1) is rectified
 // even when no ReLU layer follows it (np.maximum(0, .) at style_transfer.py:426,567).
 // `after_blob` (optional) is called as soon as a blob is complete, before the next layer is queued.
+// `observed` (optional): blobs whose data somebody reads after the pass (taps, requested maps);
+// a convolution whose only consumer is a pooling layer fused into it need not store the others.
 int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
-            const std::function<int(int)> *after_blob = nullptr, bool relu_codes = false) {
+            const std::function<int(int)> *after_blob = nullptr, bool relu_codes = false,
+            const std::vector<char> *observed = nullptr) {
     int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
@@ -667,7 +674,15 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
                 }
             }
             bool pooled = false;
-            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled, relu_codes));
+            bool unobserved = false;
+            if (pool && observed && !(*observed)[L.top_blob] && L.top_blob != relu_blob) {
+                int readers = 0;
+                for (size_t lj = li + 1; lj < e->layers.size(); ++lj)
+                    readers += e->layers[lj].type != STX_LAYER_RELU && e->layers[lj].bottom_blob == L.top_blob;
+                unobserved = readers == 1;
+            }
+            STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled, relu_codes,
+                                     unobserved));
             if (pooled) pooled_layer = pool_li;
             if (after_blob) {
                 STX_TRY((*after_blob)(L.top_blob));
@@ -1271,7 +1286,9 @@ int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int 
     STX_TRY(begin_timing(e));
     // the reference rectifies the net's last blob (style_transfer.py:426)
     const int last_blob = (int)e->blobs.size() - 1;
-    STX_TRY(forward(e, needed, needed[last_blob] ? last_blob : -1));
+    std::vector<char> observed(e->blobs.size(), 0);
+    for (int i = 0; i < n_layers; ++i) observed[want[i]] = 1;
+    STX_TRY(forward(e, needed, needed[last_blob] ? last_blob : -1, nullptr, false, &observed));
     STX_TRY(end_timing(e));
     for (int i = 0; i < n_layers; ++i) {
         const Blob &b = e->blobs[want[i]];
@@ -1500,7 +1517,9 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     };
     if (!g) STX_TRY(begin_timing(e));
     e->flop_algorithmic = e->flop_issued = 0;
-    STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true));
+    std::vector<char> observed(e->blobs.size(), 0);
+    for (const Tap &tp : order) observed[tp.blob] = 1;
+    STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true, &observed));
     if (!interleave) {
         STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
         STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
