@@ -682,12 +682,21 @@ struct SmallConvArgs {
     int K, M, H, W, n_chunks, tiles_x, x_bytes, w_bytes;
 };
 
-template <int KC, int PR>
+// VEC (plane width a multiple of 4, 16-byte aligned planes): the 64 interior columns of a patch
+// row are 16 aligned 16-byte loads and the two halo columns two dword loads -- 6 loads per thread
+// and chunk instead of 21 dword loads (the kernel reads the whole 64-channel gradient once and
+// was bound by the number of load instructions: 268 MB in 92 us).  LDS rows are laid out as
+// [3 pad][left halo][64 interior][right halo][3 pad] so that the interior is 16-byte aligned.
+template <int KC, int PR, bool VEC>
 __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
-    constexpr int PC = 64, XR = PR + 2, XC = PC + 2, NT = 256, RW = PR / 4;
+    constexpr int PC = 64, XR = PR + 2, XC = VEC ? PC + 8 : PC + 2, X0 = VEC ? 3 : 0, NT = 256, RW = PR / 4;
     constexpr int X_FLOATS = KC * XR * XC, W_FLOATS = KC * 9 * 4;
-    constexpr int NX = (X_FLOATS + NT - 1) / NT;
+    constexpr int NX = (KC * XR * (PC + 2) + NT - 1) / NT;          // dword loads per thread (!VEC)
+    constexpr int NV = KC * XR * (PC / 4);                          // 16-byte loads per chunk (VEC)
+    constexpr int NVT = (NV + NT - 1) / NT;
+    constexpr int NH = KC * XR * 2;                                 // halo dwords per chunk (VEC)
     static_assert(W_FLOATS / 4 <= NT, "one float4 of weights per thread");
+    static_assert(NH <= NT, "one halo element per thread");
     __shared__ __attribute__((aligned(16))) float Xl[X_FLOATS];
     __shared__ __attribute__((aligned(16))) float Wl[W_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -702,18 +711,42 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
         const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
-    unsigned xvoff[NX];
+    unsigned xvoff[VEC ? 1 : NX], vvoff[VEC ? NVT : 1], hvoff = kOob;
+    int vdst[VEC ? NVT : 1], hdst = 0;
+    if (VEC) {
 #pragma unroll
-    for (int n = 0; n < NX; ++n) {
-        const int e = tid + n * NT;
-        const int ci = e / (XR * XC), rem = e - ci * (XR * XC);
-        const int r = rem / XC, c = rem - r * XC;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        const bool ok = e < X_FLOATS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-        xvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+        for (int n = 0; n < NVT; ++n) {
+            const int e = tid + n * NT;                       // (channel, row, 16-byte column group)
+            const int ci = e / (XR * (PC / 4)), rem = e - ci * (XR * (PC / 4));
+            const int r = rem / (PC / 4), c4 = rem - r * (PC / 4);
+            const int yy = y0 - 1 + r, xx = x0 + 4 * c4;
+            // (W is a multiple of 4 and x0 of 64: a group is inside the row or outside it entirely)
+            const bool ok = e < NV && (unsigned)yy < (unsigned)a.H && xx < a.W;
+            vvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+            vdst[n] = e < NV ? (ci * XR + r) * XC + X0 + 1 + 4 * c4 : -1;
+        }
+        if (tid < NH) {
+            const int ci = tid / (XR * 2), rem = tid - ci * (XR * 2);
+            const int r = rem >> 1, side = rem & 1;
+            const int yy = y0 - 1 + r, xx = side ? x0 + PC : x0 - 1;
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            hvoff = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+            hdst = (ci * XR + r) * XC + X0 + (side ? PC + 1 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int e = tid + n * NT;
+            const int ci = e / (XR * XC), rem = e - ci * (XR * XC);
+            const int r = rem / XC, c = rem - r * XC;
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const bool ok = e < X_FLOATS && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            xvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+        }
     }
     const unsigned wvoff = tid < W_FLOATS / 4 ? (unsigned)tid * 16u : kOob;
-    unsigned xreg[NX];
+    unsigned xreg[VEC ? 1 : NX], hreg = 0;
+    u32x4 vreg[VEC ? NVT : 1];
     u32x4 wreg;
     auto load_stage = [&](int chunk) {
         wreg = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (unsigned)chunk * (W_FLOATS * 4u), 0);
@@ -725,22 +758,35 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
                                                    (nk > 0 ? nk : 0) * HW * 4, 0x00020000);
             xs = 0;
         }
+        if (VEC) {
 #pragma unroll
-        for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
+            for (int n = 0; n < NVT; ++n) vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, vvoff[n], xs, 0);
+            hreg = __builtin_amdgcn_raw_buffer_load_b32(rx, hvoff, xs, 0);
+        } else {
+#pragma unroll
+            for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
+        }
     };
     auto store_stage = [&]() {
         if (tid < W_FLOATS / 4) reinterpret_cast<u32x4 *>(Wl)[tid] = wreg;
+        if (VEC) {
 #pragma unroll
-        for (int n = 0; n < NX; ++n) {
-            const int e = tid + n * NT;
-            if (e < X_FLOATS) reinterpret_cast<unsigned *>(Xl)[e] = xreg[n];
+            for (int n = 0; n < NVT; ++n)
+                if (vdst[n] >= 0) *reinterpret_cast<u32x4 *>(Xl + vdst[n]) = vreg[n];
+            if (tid < NH) reinterpret_cast<unsigned *>(Xl)[hdst] = hreg;
+        } else {
+#pragma unroll
+            for (int n = 0; n < NX; ++n) {
+                const int e = tid + n * NT;
+                if (e < X_FLOATS) reinterpret_cast<unsigned *>(Xl)[e] = xreg[n];
+            }
         }
     };
     f32x4 acc[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *wl = Wl + (lane & 3);
-    const float *xl = Xl + (wave * RW) * XC + lane;
+    const float *xl = Xl + (wave * RW) * XC + X0 + lane;
 
     load_stage(0);
     store_stage();
@@ -840,7 +886,12 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
     a.x_bytes = big ? 0 : (int)xb;
     a.w_bytes = (int)(conv_small_packed_floats(K) * 4);
     const int n_wg = a.tiles_x * ceil_div(H, kSmallPR);
-    conv3x3_m4_kernel<kSmallKC, kSmallPR><<<n_wg, 256, 0, s>>>(a);
+    // 16-byte loads need 16-byte aligned rows: plane width a multiple of 4, aligned base
+    const char *novec = getenv("STX_SMALL_NOVEC");
+    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !(novec && atoi(novec)))
+        conv3x3_m4_kernel<kSmallKC, kSmallPR, true><<<n_wg, 256, 0, s>>>(a);
+    else
+        conv3x3_m4_kernel<kSmallKC, kSmallPR, false><<<n_wg, 256, 0, s>>>(a);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
