@@ -462,29 +462,36 @@ __global__ __launch_bounds__(256, 2) void gram_partial_bf3_kernel(const float *_
             __syncthreads();
         }
     }
-    // add the four waves' partial tiles in wave order through LDS (deterministic), then one
-    // coalesced write of the 64x64 tile
-    float *red = lds;                                  // 64 x 64 floats fit in a stage
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    // the four waves' partial tiles side by side in LDS (4 x 16 KB: the two stages are free now),
+    // one barrier, then every thread adds its 16 elements in wave order -- ((w0 + w1) + w2) + w3,
+    // the order of the fp32 kernel's four sequential rounds, bit for bit -- and writes them
+    float *red = lds + wave * (kGT * kGT);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float *q = red + row * kGT + j * 32 + l31;
-                        *q = w == 0 ? acc[i][j][r] : *q + acc[i][j][r];
-                    }
-        }
-        __syncthreads();
-    }
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[row * kGT + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+    static_assert(4 * kGT * kGT <= 2 * kStageFloats, "the four partial tiles must fit the stage buffers");
     float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-        reinterpret_cast<float4 *>(out)[tid + 256 * n] = reinterpret_cast<const float4 *>(red)[tid + 256 * n];
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;
+        const float4 w0 = reinterpret_cast<const float4 *>(lds)[e];
+        const float4 w1 = reinterpret_cast<const float4 *>(lds + kGT * kGT)[e];
+        const float4 w2 = reinterpret_cast<const float4 *>(lds + 2 * kGT * kGT)[e];
+        const float4 w3 = reinterpret_cast<const float4 *>(lds + 3 * kGT * kGT)[e];
+        float4 v;
+        v.x = ((w0.x + w1.x) + w2.x) + w3.x;
+        v.y = ((w0.y + w1.y) + w2.y) + w3.y;
+        v.z = ((w0.z + w1.z) + w2.z) + w3.z;
+        v.w = ((w0.w + w1.w) + w2.w) + w3.w;
+        reinterpret_cast<float4 *>(out)[e] = v;
+    }
 }
 
 // STX_GRAM=fp32 (read at every call) keeps the fp32-MFMA kernels, for A/B measurements and tests.
