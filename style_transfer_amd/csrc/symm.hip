@@ -25,14 +25,28 @@
 #include "bf16x3.h"
 #include "common.h"
 
+#ifndef STX_SYMM_SKIP
+#define STX_SYMM_SKIP 0   // timing experiments (tools/ubench/symm_bench.hip): 1 no MFMAs, 2 no split, 4 no F
+#endif                   // loads after the first steps, 8 no S stores.  Wrong results when non-zero.
+
 namespace stx {
 
 namespace {
 
 constexpr int kSM = 64;            // output channels per workgroup
 constexpr int kSN = 256;           // pixels per workgroup (64 per wave)
-constexpr int kSK = 32;            // k per LDS chunk (two MFMA steps)
-constexpr int kRowBytes = 80;      // 32 bf16 + 16 bytes of padding: conflict-free ds_read_b128
+#ifndef STX_SYMM_KSK
+#define STX_SYMM_KSK 32
+#endif
+constexpr int kSK = STX_SYMM_KSK;  // k per LDS chunk (kSK / 16 MFMA steps between two barriers)
+constexpr int kSPC = kSK / 16;     // steps per chunk
+constexpr int kSegs = kSK / 8;     // 16-byte segments per row and piece
+constexpr int kDLoads = 3 * kSM * kSegs / 256;   // 16-byte loads per thread and chunk
+constexpr int kRowBytes = 2 * kSK + 16;   // + 16 bytes of padding: conflict-free ds_read_b128
+#ifndef STX_SYMM_RING
+#define STX_SYMM_RING 3
+#endif
+constexpr int kRing = STX_SYMM_RING;      // F steps in flight per wave (kRing - 1 ahead of the one multiplied)
 constexpr int kPieceBytes = kSM * kRowBytes;
 constexpr int kChunkBytes = 3 * kPieceBytes;
 
@@ -82,26 +96,28 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
     const int n_steps = Cp / 16, n_chunks = Cp / kSK;
 
     // ---- D chunk staging: 3 pieces x 64 rows x 64 bytes = 768 16-byte segments, three per thread
-    const unsigned short *dsrc[3];
-    unsigned ddst[3];
+    const unsigned short *dsrc[kDLoads];
+    unsigned ddst[kDLoads];
 #pragma unroll
-    for (int n = 0; n < 3; ++n) {
-        const int row = tid >> 2, seg = tid & 3;
-        dsrc[n] = Dp + ((size_t)n * Cp + (m0 + row)) * Cp + seg * 8;
-        ddst[n] = (unsigned)(n * kPieceBytes + row * kRowBytes + seg * 16);
+    for (int n = 0; n < kDLoads; ++n) {
+        const int e = tid + 256 * n;                 // (piece, row, segment)
+        const int pc = e / (kSM * kSegs), rem = e - pc * (kSM * kSegs);
+        const int row = rem / kSegs, seg = rem - row * kSegs;
+        dsrc[n] = Dp + ((size_t)pc * Cp + (m0 + row)) * Cp + seg * 8;
+        ddst[n] = (unsigned)(pc * kPieceBytes + row * kRowBytes + seg * 16);
     }
-    u32x4y dreg[3];
+    u32x4y dreg[kDLoads];
     auto d_load = [&](int chunk) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) dreg[n] = *reinterpret_cast<const u32x4y *>(dsrc[n] + chunk * kSK);
+        for (int n = 0; n < kDLoads; ++n) dreg[n] = *reinterpret_cast<const u32x4y *>(dsrc[n] + chunk * kSK);
     };
     auto d_store = [&](int buf) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n) *reinterpret_cast<u32x4y *>(lds + buf * kChunkBytes + ddst[n]) = dreg[n];
+        for (int n = 0; n < kDLoads; ++n) *reinterpret_cast<u32x4y *>(lds + buf * kChunkBytes + ddst[n]) = dreg[n];
     };
 
     // ---- F fragments: step s covers channels 16 s .. 16 s + 15
-    float raw[3][2][8];       // ring of three steps in flight (two ahead of the one being multiplied)
+    float raw[kRing][2][8];   // ring of steps in flight (kRing - 1 ahead of the one being multiplied)
     auto f_load = [&](int step, int slot_) {
         // (a scalar offset must not exceed the descriptor's range: channels past C are clamped to
         // C, where every lane is out of range and reads zero)
@@ -129,8 +145,9 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     d_load(0);
-    f_load(0, 0);
-    if (n_steps > 1) f_load(1, 1);
+#pragma unroll
+    for (int r = 0; r < kRing - 1; ++r)
+        if (r < n_steps) f_load(r, r);
     d_store(0);
     if (n_chunks > 1) d_load(1);
     __syncthreads();
@@ -139,7 +156,17 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
     auto do_step = [&](int step, int slot_, int buf, int s_in_chunk) {
         bf16x8 pb[2][3], pa[2][3];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) split3_bf16(raw[slot_][j], pb[j][0], pb[j][1], pb[j][2]);
+        for (int j = 0; j < 2; ++j) {
+            if (STX_SYMM_SKIP & 2) {
+                typedef float f32x4s __attribute__((ext_vector_type(4)));
+                const float *x = raw[slot_][j];
+                pb[j][0] = __builtin_bit_cast(bf16x8, (f32x4s){x[0], x[1], x[2], x[3]});
+                pb[j][1] = __builtin_bit_cast(bf16x8, (f32x4s){x[4], x[5], x[6], x[7]});
+                pb[j][2] = pb[j][0];
+            } else {
+                split3_bf16(raw[slot_][j], pb[j][0], pb[j][1], pb[j][2]);
+            }
+        }
         const unsigned char *base = lds + buf * kChunkBytes + a_off + s_in_chunk * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -149,16 +176,23 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split6(pa[i], pb[j], acc[i][j]);
+            for (int j = 0; j < 2; ++j) {
+                if (STX_SYMM_SKIP & 1) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) acc[i][j][q] += (float)(pa[i][q][0] + pb[j][q][1]);
+                    continue;
+                }
+                acc[i][j] = mfma_split6(pa[i], pb[j], acc[i][j]);
+            }
     };
 
-    // three steps per trip so that the ring slot is a compile-time constant; a chunk is two steps
+    // three steps per trip so that the ring slot is a compile-time constant; a chunk is kSPC steps
     int step = 0;
     auto advance = [&](int slot_) {
-        const int chunk = step >> 1, s_in = step & 1, buf = chunk & 1;
-        if (step + 2 < n_steps) f_load(step + 2, (slot_ + 2) % 3);
+        const int chunk = step / kSPC, s_in = step % kSPC, buf = chunk & 1;
+        if (step + kRing - 1 < n_steps && !(STX_SYMM_SKIP & 4)) f_load(step + kRing - 1, (slot_ + kRing - 1) % kRing);
         do_step(step, slot_, buf, s_in);
-        if (s_in == 1) {
+        if (s_in == kSPC - 1) {
             // the other buffer was last read in the previous chunk, which every wave has left
             if (chunk + 1 < n_chunks) d_store(buf ^ 1);
             if (chunk + 2 < n_chunks) d_load(chunk + 2);
@@ -167,9 +201,9 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
         ++step;
     };
     while (step < n_steps) {
-        advance(0);
-        if (step < n_steps) advance(1);
-        if (step < n_steps) advance(2);
+#pragma unroll
+        for (int r = 0; r < kRing; ++r)
+            if (step < n_steps) advance(r);
     }
 
     // ---- S tile out, |S| summed: D register r of a block is row (r & 3) + 8 (r >> 2) + 4 g
@@ -193,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
                 const float v = acc[i][j][r];
                 asum += ok ? fabsf(v) : 0.f;
                 const unsigned vo = ok ? (unsigned)((4 * g) * HW + px) * 4u : kOob;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rrow, vo, so, 0);
+                if (!(STX_SYMM_SKIP & 8))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rrow, vo, so, 0);
             }
         }
 #pragma unroll
