@@ -181,6 +181,15 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
                      const int roll_xy[2], const int start_yx[2], const stx_tap *taps, int n_taps,
                      double *loss_out, float *grad_out, int grad_mem, int sync_now);
 
+/* Zero-copy hand-off for callers that produce the tile on the engine's own GPU (the tile farm
+ * cuts tiles with stx_image_cut_tile): *tile_in is the engine's input blob sized for a
+ * [3][th][tw] tile, *grad_out the blob its gradient is left in.  Passing exactly these pointers
+ * as `img` / `grad_out` of stx_sc_grad_tile (same th, tw) skips the two device-to-device copies
+ * of the call.  The pointers are valid until a larger tile is evaluated on this engine: query
+ * them again before every use.  (The reference copies every tile into and out of POSIX shared
+ * memory, style_transfer.py:634-643.) */
+int stx_tile_buffers(stx_engine *e, int th, int tw, float **tile_in, float **grad_out);
+
 /* Lower-triangular Gram of a feature map, F F^T / (C*h*w), upper triangle zero: gram_matrix
  * (num_utils.py:143-147) as used for the style targets (style_transfer.py:534). */
 int stx_gram_matrix(stx_engine *e, const float *feat, int feat_mem, int channels, int hw,

@@ -1717,14 +1717,14 @@ int graph_replay(stx_engine *e, TileGraph *g, const TileCall &c, double *loss_ou
     if (n) STX_TRY(set_ints_launch(e->stream, g->dyn, vals, n));
     Blob &in = e->blobs[e->layers[0].top_blob];
     const size_t bytes = (size_t)in.channels * c.th * c.tw * sizeof(float);
-    STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, bytes));
+    if (c.img != in.data.ptr) STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, bytes));   // (stx_tile_buffers)
     STX_HIP(hipEventRecord(e->ev_start, e->stream));
     STX_HIP(hipGraphLaunch(g->exec, e->stream));
     STX_HIP(hipEventRecord(e->ev_stop, e->stream));
     e->timed = true;
     e->flop_algorithmic = g->flop_algorithmic;
     e->flop_issued = g->flop_issued;
-    STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, bytes));
+    if (c.grad_out != in.diff.ptr) STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, bytes));
     PendingLoss pl;
     pl.out = loss_out;
     pl.terms = g->terms;
@@ -1750,11 +1750,13 @@ int sc_grad_eager(stx_engine *e, const TileCall &c, double *loss_out) {
     TilePlan plan;
     STX_TRY(sc_grad_prepare(e, c, plan));
     Blob &in = e->blobs[e->layers[0].top_blob];
-    STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, in.count() * sizeof(float)));
+    // (a tile handed over in the engine's own buffers, stx_tile_buffers, needs no copies)
+    if (c.img != in.data.ptr) STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, in.count() * sizeof(float)));
     PendingLoss pl;
     pl.out = loss_out;
     STX_TRY(sc_grad_run(e, c, plan, pl, nullptr));
-    STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, in.count() * sizeof(float)));
+    if (c.grad_out != in.diff.ptr)
+        STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, in.count() * sizeof(float)));
     e->pending.push_back(std::move(pl));
     ++e->n_eager;
     return STX_OK;
@@ -1819,6 +1821,18 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     }
     STX_TRY(rc);
     if (sync_now) return do_sync(e);
+    return STX_OK;
+}
+
+int stx_tile_buffers(stx_engine *e, int th, int tw, float **tile_in, float **grad_out) {
+    if (!e || th <= 0 || tw <= 0 || !tile_in || !grad_out) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    Blob &in = e->blobs[e->layers[0].top_blob];
+    const size_t bytes = (size_t)in.channels * th * tw * sizeof(float);
+    STX_TRY(in.data.ensure(bytes));
+    STX_TRY(in.diff.ensure(bytes));
+    *tile_in = in.data.f();
+    *grad_out = in.diff.f();
     return STX_OK;
 }
 

@@ -319,6 +319,15 @@ class TileEngine:
             t.dd_weight = float(dd_weight.get(name, 0.0)) if t.is_dd and dd_weight else 0.0
         return taps, len(names)
 
+    def io_buffers(self, th, tw):
+        """(tile, gradient) DeviceArray views of the engine's own input blob and of the blob its
+        gradient is left in: a tile written into the first and evaluated with grad_out = the
+        second needs no copies (stx_tile_buffers).  Query before every use."""
+        tin, gout = ctypes.c_void_p(), ctypes.c_void_p()
+        lib.call('stx_tile_buffers', self.handle, int(th), int(tw), ctypes.byref(tin), ctypes.byref(gout))
+        return (DeviceArray.from_pointer(self, tin.value, (3, th, tw)),
+                DeviceArray.from_pointer(self, gout.value, (3, th, tw)))
+
     def sc_grad_tile_async(self, img, start, roll, content_layers, style_layers, layer_weights,
                            content_weight, style_weight, grad_out=None, dd_layers=(),
                            dd_weight=None):

@@ -83,6 +83,7 @@ class TileFarm:
         self.force_staging = bool(int(os.environ.get('STX_FARM_FORCE_STAGING', '0'))) \
             if force_staging is None else bool(force_staging)
         self.owns_engines = engines is None
+        self.zero_copy = not bool(int(os.environ.get('STX_FARM_COPY_TILES', '0')))
         self.devices = list(devices)
         self.weights = weights
         self.max_engines = len(self.devices) * max(1, streams_per_device) \
@@ -310,13 +311,16 @@ class TileFarm:
         n = len(engines)
         master = self.master
         jobs, workers = [], []
+        # every engine evaluates at most one tile this step: the master can cut straight into the
+        # engines' input blobs and stitch straight out of their gradient blobs (no copies)
+        one_each = len(rects) <= n and self.zero_copy
         for t, rect in enumerate(rects):
             ei, slot = t % n, t // n
             eng = engines[ei]
             th, tw = rect[1] - rect[0], rect[3] - rect[2]
             if eng.device == master.device and not (self.force_staging and ei != 0):
                 # the master's own GPU (any stream): its buffers are directly addressable
-                tile, tgrad = self._tile_buffers(ei, slot, th, tw)
+                tile, tgrad = eng.io_buffers(th, tw) if one_each else self._tile_buffers(ei, slot, th, tw)
             else:
                 tile, tgrad = self._staging_buffers(t, th, tw)
             image_ops.cut_tile(master, img, roll, rect, tile)

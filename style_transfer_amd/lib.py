@@ -77,6 +77,7 @@ SIGNATURES = {
                           ctypes.POINTER(_vp), _i],
     'stx_sc_grad_tile': [_vp, _vp, _i, _i, _i, c_int_p, c_int_p, ctypes.POINTER(Tap), _i,
                          c_double_p, _vp, _i, _i],
+    'stx_tile_buffers': [_vp, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp)],
     'stx_gram_matrix': [_vp, _vp, _i, _i, _i, _vp, _i],
     'stx_image_cut_tile': [_vp, _vp, _i, _i, c_int_p, _i, _i, _i, _i, _vp],
     'stx_image_put_tile': [_vp, _vp, _i, _i, c_int_p, _i, _i, _i, _i, _vp],

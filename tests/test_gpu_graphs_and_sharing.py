@@ -178,3 +178,31 @@ def test_lazy_loss_and_stream_ordered_gradient(monkeypatch):
         assert np.array_equal(copy.get(), g_sync.get())
         copy.free()
     farm.close()
+
+
+def test_zero_copy_tiles_equal_copied_tiles():
+    """One tile per engine: the master cuts straight into the engines' input blobs and stitches out
+    of their gradient blobs (stx_tile_buffers).  Same bits as with separate tile buffers and the
+    two device-to-device copies per tile."""
+    from style_transfer_amd.farm import TileFarm
+    require_gpu()
+    net = builtin_net('vgg19')
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(8)
+    img = rng.uniform(-110, 120, (3, 128, 144)).astype(np.float32)
+    results = []
+    for zero_copy in (True, False):
+        farm = TileFarm(net, [0], weights, verbose=False)
+        farm.zero_copy = zero_copy
+        eng = farm.master
+        np.random.seed(1)
+        contents = [farm.prepare_features_device(img, CL, 96, passes=2)]
+        feats = farm.prepare_features_device(img[:, :64, :64], SL, 96, passes=1)
+        farm.set_contents_and_styles(contents, [{l: farm.gram_matrix(f) for l, f in feats.items()}])
+        d_img, d_grad = eng.to_device(img), eng.empty(img.shape).zero()
+        losses = [farm.eval_sc_grad(d_img, d_grad, (8 * k, -16), CL, SL, {}, CW, SW, 96) for k in range(3)]
+        assert farm.tile_evals == 12 and bool(farm._tiles) != zero_copy
+        results.append((losses, d_grad.get()))
+        farm.close()
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
