@@ -67,37 +67,50 @@ __device__ __forceinline__ int wrap(int v, int n) {
     return v < 0 ? v + n : v;
 }
 
+// One workgroup row per (channel, tile row): the wrapped source row is a scalar, a lane's column
+// one add and one conditional subtract (the flat-index form spent its time in 64-bit divisions:
+// 15 us for a 12.6 MB tile).
 template <bool PUT>
 __global__ __launch_bounds__(256) void tile_move_kernel(float *__restrict__ full, int H, int W,
                                                         int rx, int ry, int y0, int x0, int th,
                                                         int tw, float *__restrict__ tile) {
-    const size_t total = (size_t)3 * th * tw;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = i % tw;
-        const int y = (i / tw) % th;
-        const int c = i / ((size_t)tw * th);
-        const size_t j = ((size_t)c * H + wrap(y0 + y - ry, H)) * W + wrap(x0 + x - rx, W);
+    const int cy = blockIdx.y, c = cy / th, y = cy - c * th;
+    const float *const frow_c = full + ((size_t)c * H + wrap(y0 + y - ry, H)) * W;
+    float *const frow = const_cast<float *>(frow_c);
+    float *const trow = tile + (size_t)cy * tw;
+    const int xs = wrap(x0 - rx, W);                       // source column of the tile's column 0
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < tw; x += gridDim.x * 256) {
+        int xx = xs + x % W;                               // (a tile is never wider than the image,
+        xx = xx >= W ? xx - W : xx;                        //  but the arithmetic does not rely on it)
         if (PUT)
-            full[j] = tile[i];
+            frow[xx] = trow[x];
         else
-            tile[i] = full[j];
+            trow[x] = frow[xx];
     }
 }
 
+static dim3 tile_move_grid(int th, int tw) { return dim3((unsigned)std::min(8, (tw + 255) / 256), (unsigned)(3 * th)); }
+
 int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int ry, int y0, int x0,
                     int th, int tw, float *tile) {
-    const size_t total = (size_t)3 * th * tw;
-    tile_move_kernel<false><<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
-        const_cast<float *>(img), H, W, rx, ry, y0, x0, th, tw, tile);
+    if (3 * (long)th > 65535) {
+        set_error("cut_tile: tile of %d rows is too tall", th);
+        return STX_ERR_UNSUPPORTED;
+    }
+    tile_move_kernel<false><<<tile_move_grid(th, tw), 256, 0, s>>>(const_cast<float *>(img), H, W, rx, ry, y0,
+                                                                  x0, th, tw, tile);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
 
 int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, int y0, int x0,
                     int th, int tw, const float *tile) {
-    const size_t total = (size_t)3 * th * tw;
-    tile_move_kernel<true><<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
-        grad, H, W, rx, ry, y0, x0, th, tw, const_cast<float *>(tile));
+    if (3 * (long)th > 65535) {
+        set_error("put_tile: tile of %d rows is too tall", th);
+        return STX_ERR_UNSUPPORTED;
+    }
+    tile_move_kernel<true><<<tile_move_grid(th, tw), 256, 0, s>>>(grad, H, W, rx, ry, y0, x0, th, tw,
+                                                                 const_cast<float *>(tile));
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
