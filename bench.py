@@ -23,14 +23,17 @@ as xGMI peer copies ordered by events, no host wait inside a step) -- is timed o
 and step loop after the ranks have finished, and reported as the `farm` sub-record.
 
 The line also carries
-  roofline      the matrix-core work the kernels ISSUE for the four tile-iterations of one GPU
-                (convolutions through Winograd F(2x2,3x3) issue 4/9 of a direct convolution's
-                MFMAs; Gram and SYMM products in full) over the GPU time of that concurrent group
-                of stx_sc_grad_tile calls -- HIP events on each engine's own stream inside the
-                timed region, the longest of the four spans -- against the fp32 MFMA peak, so that
-                frac <= 1 by construction; `bound_ms` is the time the same work takes at that
-                peak.  The SURVEY 8d figure (1 514 240 FLOP per tile pixel, every convolution
-                counted as a direct one) is kept beside it as achieved_direct_equiv;
+  roofline      the time the kernels' own instructions need on the matrix pipe, in fp32-MFMA FLOP,
+                for the four tile-iterations of one GPU (convolutions through Winograd F(2x2,3x3)
+                issue 4/9 of a direct convolution's MFMAs; Gram and SYMM run as six bf16 MFMAs per
+                16 k and are counted at the 0.375 of their fp32 pipe time that this occupies) over
+                the GPU time of that concurrent group of stx_sc_grad_tile calls -- HIP events on
+                each engine's own stream inside the timed region, the longest of the four spans --
+                against the fp32 MFMA peak, so that frac <= 1 by construction; `bound_ms` is the
+                time the same work takes at that peak; `frac_round2_accounting` counts Gram and
+                SYMM in full, as round 2 did.  The SURVEY 8d figure (1 514 240 FLOP per tile pixel,
+                every convolution counted as a direct one) is kept beside it as
+                achieved_direct_equiv;
   steady        the same step loop run for at least 5 s after the timed region;
   wall_clock_s  the WHOLE `--size 2048 --tile-size 1024` command-line run (7 pyramid scales,
                 800 iterations, 1400 tile-iterations, preprocessing and PNG output included) on
