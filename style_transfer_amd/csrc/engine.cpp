@@ -184,7 +184,9 @@ using namespace stx;
 struct stx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;            // loss terms of the tapped blobs (overlaps the backward pass)
+    hipStream_t side = nullptr;            // where the loss terms of the current call run: stream or side2
+    hipStream_t side2 = nullptr;           // second stream for them (small tiles, see stx_sc_grad_tile)
+    int side_mode = 0;                     // STX_SIDE_STREAM: 0 / unset never, 1 always, "auto" (-1): small tiles
     hipEvent_t ev_fwd = nullptr;
     std::vector<hipEvent_t> ev_tap;
     std::vector<std::unique_ptr<DevBuf>> sgrad_tap;
@@ -958,10 +960,13 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
     // (STX_SIDE_STREAM=1).  Measured on MI355X this is 1.7 % SLOWER (13.24 vs 13.02 ms per 1024^2
     // tile): the conv kernels already keep every CU's matrix pipe ~90 % busy, so co-resident
     // Gram / SYMM workgroups only displace conv workgroups.  Default: in order on one stream.
-    if (getenv("STX_SIDE_STREAM") && atoi(getenv("STX_SIDE_STREAM")) == 1)
-        STX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    else
-        e->side = e->stream;
+    // STX_SIDE_STREAM=auto does it for tiles of up to 512 x 512 only, where the chip is not full:
+    // stepping one scale in isolation gains (256 px 8 %, 362 px 6 %, 512 px 3 %,
+    // tools/scale_steps.py), the whole `--size 2048` run does not (5.94 vs 5.90 s of stepping, three
+    // alternating pairs on one box), so it stays a switch.  The choice is made per call.
+    if (const char *env = getenv("STX_SIDE_STREAM")) e->side_mode = !strcmp(env, "auto") ? -1 : atoi(env) != 0;
+    STX_HIP(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+    e->side = e->stream;
     STX_HIP(hipEventCreateWithFlags(&e->ev_fwd, hipEventDisableTiming));
     STX_HIP(hipEventCreate(&e->ev_start));
     STX_HIP(hipEventCreate(&e->ev_stop));
@@ -1021,11 +1026,11 @@ void stx_engine_destroy(stx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->side && e->side != e->stream) (void)hipStreamSynchronize(e->side);
+    if (e->side2) (void)hipStreamSynchronize(e->side2);
     for (auto &b : e->sgrad_tap) b->release();
     for (hipEvent_t ev : e->ev_tap) (void)hipEventDestroy(ev);
     if (e->ev_fwd) (void)hipEventDestroy(e->ev_fwd);
-    if (e->side && e->side != e->stream) (void)hipStreamDestroy(e->side);
+    if (e->side2) (void)hipStreamDestroy(e->side2);
     for (Blob &b : e->blobs) {
         b.data.release();
         b.diff.release();
@@ -1523,7 +1528,9 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     if (!interleave) {
         STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
         STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
-        for (size_t k = 0; k < order.size(); ++k) STX_TRY(launch_terms(k));
+        // (shallowest tap first, the order the interleaved schedule queues them in: the host adds
+        // the loss terms up in queueing order, in double precision, and must get the same bits)
+        for (size_t k = order.size(); k-- > 0;) STX_TRY(launch_terms(k));
     }
 
     // Adds the terms of tap k to its blob's diff with stand-alone kernels (used for the deepest
@@ -1776,6 +1783,8 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     STX_TRY(e->set_device());
     const TileCall c{img, img_mem, th, tw, roll_xy ? roll_xy[0] : 0, roll_xy ? roll_xy[1] : 0,
                      {start_yx[0], start_yx[1]}, taps, n_taps, grad_out, grad_mem};
+    // loss terms beside the backward pass on small tiles (they cannot fill the chip on their own)
+    e->side = e->side_mode == 1 || (e->side_mode < 0 && (long)th * tw <= 512L * 512L) ? e->side2 : e->stream;
     // Recorded launch graphs: a key's first evaluations run eagerly (they size buffers, pack
     // filter banks and may time kernel variants -- none of which can be recorded), the next one
     // is recorded, later ones replay the recording for as long as no device buffer moved.
@@ -2235,7 +2244,7 @@ int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed) {
     if (!e || (!buf && buf_len)) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     STX_HIP(hipStreamSynchronize(e->stream));
-    STX_HIP(hipStreamSynchronize(e->side));
+    STX_HIP(hipStreamSynchronize(e->side2));
     std::string out;
     for (auto &pe : e->prof) {
         float ms = 0.f;

@@ -25,6 +25,7 @@ def test_transfer_multiscale_matches_reference_run(golden, recorded, monkeypatch
     from argparse import Namespace
     if recorded:
         monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '1')
+        monkeypatch.setenv('STX_SIDE_STREAM', '0')      # (the default; a second stream is never recorded)
     argv = str(golden['e2e.argv']).split()
     state = Namespace()
     args = parse_args(state, argv, config_py=False)

@@ -46,6 +46,7 @@ def test_replayed_graph_equals_eager_calls(model, monkeypatch):
         calls.append((th, tw, start, roll, rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)))
     results = {}
     monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')      # (default: 300 evaluations before a recording)
+    monkeypatch.setenv('STX_SIDE_STREAM', '0')          # (the default; a second stream is never recorded)
     for mode in ('0', '1'):
         monkeypatch.setenv('STX_GRAPH', mode)
         eng = TileEngine(net, 0, weights)
@@ -80,6 +81,7 @@ def test_graph_instances_between_syncs_and_rerecording_after_new_targets(monkeyp
     from style_transfer_amd.engine import TileEngine
     require_gpu()
     monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')
+    monkeypatch.setenv('STX_SIDE_STREAM', '0')
     net = builtin_net('vgg19')
     eng = TileEngine(net, 0, synthetic_weights(net.as_dicts(), 0))
     rng = np.random.RandomState(2)
@@ -159,6 +161,7 @@ def test_lazy_loss_and_stream_ordered_gradient(monkeypatch):
     from style_transfer_amd.farm import LazyLoss, TileFarm
     require_gpu()
     monkeypatch.setenv('STX_GRAPH_MIN_EAGER', '2')
+    monkeypatch.setenv('STX_SIDE_STREAM', '0')
     net = builtin_net('vgg19')
     weights = synthetic_weights(net.as_dicts(), 0)
     rng = np.random.RandomState(4)
@@ -206,3 +209,33 @@ def test_zero_copy_tiles_equal_copied_tiles():
         farm.close()
     assert results[0][0] == results[1][0]
     assert np.array_equal(results[0][1], results[1][1])
+
+
+@pytest.mark.parametrize('model', ['vgg19', 'vgg16_avgpool'])
+def test_loss_terms_on_a_second_stream_change_nothing(model, monkeypatch):
+    """Tiles of up to 512 x 512 run Gram / SYMM / content sums on a second HIP stream beside the
+    rest of the forward and the backward pass (they cannot fill the chip on their own); the
+    backward walk waits for each tap's event.  Same kernels, same order of additions: identical
+    to the single-stream schedule, repeatedly (a missing dependency would show as a race)."""
+    from style_transfer_amd.engine import TileEngine
+    require_gpu()
+    net = builtin_net(model)
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(12)
+    th, tw = 136, 200
+    tiles = [rng.uniform(-110, 120, (3, th, tw)).astype(np.float32) for _ in range(3)]
+    results = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('STX_SIDE_STREAM', mode)
+        eng = TileEngine(net, 0, weights)
+        eng.set_contents_and_styles(*_targets(eng, (th + 8, tw), np.random.RandomState(3)))
+        out = []
+        for rep in range(4):
+            for tile in tiles:
+                loss, grad = eng.sc_grad_tile(tile, (8, 0), (16, -8), CL, SL, {'conv3_1': 0.5}, CW, SW)
+                out.append((loss, grad.copy()))
+        results[mode] = out
+        eng.close()
+    for (la, ga), (lb, gb) in zip(results['0'], results['1']):
+        assert la == lb
+        assert np.array_equal(ga, gb)
