@@ -56,6 +56,7 @@ sys.path.insert(0, REPO)
 TILE = 1024
 FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+NOMINAL_CLOCK_MHZ = 2400.0
 TILES_PER_GPU = 4
 GRIDS = {1: (2, 2), 2: (2, 4), 4: (4, 4), 8: (4, 8)}      # tile grid of the image per world size
 CONTENT_LAYERS = ['conv4_2']
@@ -147,6 +148,7 @@ class FarmJob:
         self.rng = np.random.RandomState(0)
         self.opt = AdamOptimizer(eng, self.img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
         self.group_ms = []
+        self.clock = None
         self.tiles_per_step = rows * cols
 
     def step(self):
@@ -171,17 +173,25 @@ class FarmJob:
         for e in self.farm.engines:
             e.sync()
 
-    def timed(self, steps, warmup):
+    def timed(self, steps, warmup, clock_marks=False):
         for _ in range(warmup):
             self.step()
         self.fence()
         self.group_ms.clear()
+        # (clock_marks: the engines record the shader clock twice per tile evaluation, 20 us each --
+        # the second, longer measurement only, never the headline's timed steps)
+        engines = self.farm.engines[:self.tiles_per_step] if clock_marks else []
+        for e in engines:
+            e.clock_marks(True)
         t0 = time.perf_counter()
         loss = None
         for _ in range(steps):
             loss = self.step()
         self.fence()
-        return time.perf_counter() - t0, loss
+        elapsed = time.perf_counter() - t0
+        if clock_marks:
+            self.clock = clock_summary(engines)
+        return elapsed, loss
 
     def graph_counters(self):
         from style_transfer_amd import lib
@@ -275,6 +285,33 @@ GRAM_SYMM_FLOP_PER_TILE_PIXEL = int(2 * 2 * 4096 * (4 + 0.25))
 BF16X3_PIPE_TIME = 6 * 32 / (8 * 64)    # six bf16 MFMAs (32 cycles) per 16 k instead of eight fp32 ones (64)
 
 
+def clock_summary(engines):
+    """Reads and switches off the engines' clock marks: {'mhz': median, 'p10', 'p90', 'min', 'max',
+    'samples'} or None."""
+    mhz = []
+    for e in engines:
+        mhz += [m for m in e.clock_marks_read() if m > 0]
+        e.clock_marks(False)
+    if not mhz:
+        return None
+    return {'mhz': float(np.median(mhz)), 'p10': float(np.percentile(mhz, 10)),
+            'p90': float(np.percentile(mhz, 90)), 'min': float(np.min(mhz)), 'max': float(np.max(mhz)),
+            'samples': len(mhz)}
+
+
+def add_clock(roofline, clock):
+    """roofline.clock_mhz (+ percentiles), peak_at_clock, frac_at_clock from a clock_summary."""
+    if not clock:
+        return
+    # (a reading is good to about 3 %: the median may come out above the part's 2.4 GHz; never credit more)
+    peak_at_clock = PEAK_FP32_MFMA_TFLOPS * min(clock['mhz'], NOMINAL_CLOCK_MHZ) / NOMINAL_CLOCK_MHZ
+    roofline.update({'clock_mhz': clock['mhz'], 'clock_mhz_p10': clock['p10'],
+                     'clock_mhz_p90': clock['p90'], 'clock_mhz_min': clock['min'],
+                     'clock_mhz_max': clock['max'], 'clock_samples': clock['samples'],
+                     'peak_at_clock': peak_at_clock,
+                     'frac_at_clock': roofline['achieved'] / peak_at_clock})
+
+
 def roofline_record(eng, avg_group_ms):
     """Matrix-pipe work of one GPU's four concurrent tile evaluations over their HIP-event span,
     against the fp32 MFMA peak.  Every term is the time the kernels' own instructions need on the
@@ -310,7 +347,12 @@ def roofline_record(eng, avg_group_ms):
                     'F(2x2,3x3) convolutions issue 4/9 of a direct convolution; Gram and SYMM run as '
                     'six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 form and are '
                     'counted at that) over the HIP-event time of the launch group, against the fp32 '
-                    'MFMA peak at 2.4 GHz; frac_round2_accounting counts Gram and SYMM in full as '
+                    'MFMA peak at 2.4 GHz; clock_mhz is the shader clock during the second, longer measurement '
+                    '(`steady`; stx_clock_marks: two 20-microsecond readings of core cycles against the '
+                    '100 MHz counter per tile evaluation, each good to about 3 %; the median), peak_at_clock '
+                    'the fp32 MFMA peak at min(that clock, 2.4 GHz) and frac_at_clock = achieved / '
+                    'peak_at_clock; '
+                    'frac_round2_accounting counts Gram and SYMM in full as '
                     'round 2 did (they ran on the fp32 pipe then); achieved_direct_equiv credits '
                     'every convolution as a direct one (SURVEY 8d: 1 514 240 FLOP per tile pixel) '
                     'and is not a roofline fraction; traffic is a replay of the committed PMC '
@@ -421,7 +463,8 @@ def bench_single(opts, net, weights, device_index, rows, cols):
     line = base_line(opts, 1, rows, cols, elapsed, loss, job.eng, timed_group_ms)
     if opts.steady_seconds > 0:
         n_steady = max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))
-        dt, _ = job.timed(n_steady, 0)
+        dt, _ = job.timed(n_steady, 0, clock_marks=True)
+        add_clock(line['roofline'], job.clock)
         line['steady'] = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
                           'value': job.tiles_per_step * n_steady / dt, 'unit': 'tile-iterations/s'}
     line['graphs'] = job.graph_counters()
@@ -564,22 +607,29 @@ def bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_on
 
     # ---- a second, longer measurement of the same loop (the timed region above is short)
     steady = None
+    clock = None
     if opts.steady_seconds > 0:
         t = torch.tensor([max(1, int(np.ceil(opts.steady_seconds / (elapsed / opts.steps))))],
                          dtype=torch.int64, device=wire)
         dist.broadcast(t, 0)
         n_steady = int(t[0])
         fence()
+        if rank == 0:
+            for e in engines:
+                e.clock_marks(True)
         t1 = time.perf_counter()
         for _ in range(n_steady):
             step()
         fence()
         dt = time.perf_counter() - t1
+        if rank == 0:
+            clock = clock_summary(engines)
         steady = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
                   'value': len(rects) * n_steady / dt, 'unit': 'tile-iterations/s'}
     line = None
     if rank == 0:
         line = base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms)
+        add_clock(line['roofline'], clock)
         if steady is not None:
             line['steady'] = steady
     # every rank lets go of its GPU before rank 0 goes on alone (farm and whole-run legs drive

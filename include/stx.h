@@ -342,6 +342,19 @@ int stx_last_tile_ms(stx_engine *e, float *ms);
  * 4/9 of it).  Gram / SYMM products are not included. */
 int stx_last_tile_flops(stx_engine *e, double *algorithmic, double *issued);
 
+/* The shader clock the GPU sustains while it works (measurement only; nothing in the reference
+ * corresponds).  While stx_clock_marks is on, every stx_sc_grad_tile of this engine queues two ONE-WAVE
+ * kernels on its stream -- after the forward pass and at the end of the backward pass -- that read
+ * the core-cycle counter and the constant 100 MHz counter, doze for 20 microseconds and read them
+ * again: the clock at that moment, with whatever the GPU's other streams are running.  (A probe
+ * that runs beside the work for its whole length would hold one of the hardware queues the streams
+ * are multiplexed onto.)  stx_clock_marks_read synchronises the stream, returns the marks recorded
+ * since the last read in MHz, oldest first (*n_values <= max_values; at most 8192 are kept) and
+ * clears them.  bench.py switches them on for its second, longer measurement only: the fp32 MFMA
+ * peak scales with this clock, which depends on the kernels AND on their operands' bits. */
+int stx_clock_marks(stx_engine *e, int on);
+int stx_clock_marks_read(stx_engine *e, double *mhz, int max_values, int *n_values);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,13 @@ int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int t
                       const ConvConfig &cfg, float *packed);
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
+// 1-D Winograd on the bf16 matrix cores with three-piece operands (conv_bf3.hip); config id 300.
+ConvConfig bf3_config();
+size_t bf3_packed_floats(int K, int M);
+int bf3_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed);
+int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+bool bf3_usable(const ConvProblem &p);      // what the kernel takes (shape, epilogue, addressing)
+
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
 ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16
 int wino2_pick_geometry(int H, int W);
@@ -277,6 +284,7 @@ int inject_content_launch(hipStream_t s, float *diff, const float *feat, const f
                           const ContentWindow &win, const float *sums, float coef, bool accumulate);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
 int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n);
+int clock_mark_launch(hipStream_t s, long long *out, long long ticks);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
 int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,
                          float *out_b);

@@ -41,7 +41,9 @@ namespace stx {
 #ifdef STX_WINO2_TIMING   // cycle counters for tools/ubench/wino2_bench.hip
 __device__ long long g_wino2_timing[8][8];
 #define STX_T(var) const long long var = clock64()
+#define STX_TW(var) const long long var = wall_clock64()
 #else
+#define STX_TW(var) [[maybe_unused]] const long long var = 0
 #define STX_T(var) [[maybe_unused]] const long long var = 0
 #endif
 
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     int chunk = c_begin;
     [[maybe_unused]] long long t_work = 0;
     STX_T(t_begin);
+    STX_TW(w_begin);
     // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
     // of the hand-over and of the operand reads is a register plus an immediate
     // k-step 0 operands of the first chunk; from then on every chunk leaves those of its
@@ -433,6 +436,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         cur ^= 1;
     }
     STX_T(t_main_end);
+    STX_TW(w_main_end);
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
         cur ^= 1;
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 #undef STX_PK_SUB
 #ifdef STX_WINO2_TIMING
     if (blockIdx.x == gridDim.x - 3 && lane == 0) {     // a workgroup of the last round
-        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = 0;   // (the barrier is inside the chunk now)
+        g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = w_main_end - w_begin;   // 100 MHz ticks
         g_wino2_timing[wave][3] = t_main_end - t_begin;
         g_wino2_timing[wave][4] = t_begin - t_start;
         g_wino2_timing[wave][6] = t_loads - t_start, g_wino2_timing[wave][7] = t_stored - t_loads;

@@ -186,6 +186,9 @@ struct stx_engine {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // where the loss terms of the current call run: stream or side2
     hipStream_t side2 = nullptr;           // second stream for them (small tiles, see stx_sc_grad_tile)
+    bool clock_marks = false;              // stx_clock_marks: two marks per tile evaluation
+    DevBuf marks_buf;
+    int marks_used = 0;
     int side_mode = 0;                     // STX_SIDE_STREAM: 0 / unset never, 1 always, "auto" (-1): small tiles
     hipEvent_t ev_fwd = nullptr;
     std::vector<hipEvent_t> ev_tap;
@@ -376,7 +379,7 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
     }
-    const int key = dir * 1024 + (cfg.id >= 200 ? 200 : cfg.id);   // both 2-D geometries share a bank
+    const int key = dir * 1024 + (cfg.id >= 300 ? 300 : cfg.id >= 200 ? 200 : cfg.id);   // the 2-D geometries share a bank
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
         if (e->recording) {
@@ -520,7 +523,11 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
     // chosen kernel puts on the matrix cores (tile padding not counted)
     const double direct = 2.0 * p.M * p.K * p.ksize * p.ksize * (double)p.H * p.W;
     e->flop_algorithmic += direct;
-    e->flop_issued += cfg.id >= 200 ? direct * 4.0 / 9.0 : cfg.id >= 100 ? direct * 2.0 / 3.0 : direct;
+    // (id 300: 6 of 9 multiplies, each as six bf16 products of 1/16 of an fp32 MFMA's time per k)
+    e->flop_issued += cfg.id >= 300   ? direct * (6.0 / 9.0) * 0.375
+                      : cfg.id >= 200 ? direct * 4.0 / 9.0
+                      : cfg.id >= 100 ? direct * 2.0 / 3.0
+                                      : direct;
     if (cfg.id >= 100) return wino_launch(e->stream, cfg, p, conv_splitk_factor(cfg, p, true));
     return conv_launch(e->stream, cfg, p, true);
 }
@@ -529,9 +536,20 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
 // eight-wave 2-D Winograd kernel does, the four-wave one (ids 210+) writes the pooled values only.
 static bool conv_writes_pool_codes(const ConvConfig &cfg) { return cfg.id >= 200 && cfg.id < 210; }
 
+// STX_CONV_BF3=1: plain 3x3 layers with at least 128 input channels and a plane that fills the chip
+// run on the bf16 matrix cores with three-piece operands (conv_bf3.hip) -- not the layers whose
+// pooling is fused into the convolution, not the loss-injecting ones.  Read at every call.
+static bool bf3_wanted(const ConvProblem &p, bool fused_pool, bool inject) {
+    const char *env = getenv("STX_CONV_BF3");
+    if (!env || atoi(env) == 0 || fused_pool || inject || p.mask_codes) return false;
+    if (p.K < (atoi(env) > 1 ? atoi(env) : 128) || !bf3_usable(p)) return false;
+    const ConvConfig c = bf3_config();
+    return (long)ceil_div(p.M, c.bm) * ceil_div(p.H, c.pr) * ceil_div(p.W, c.pc) >= 256;
+}
+
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
-    return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
+    return cfg.id >= 200 && cfg.id < 300 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
 }
 
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
@@ -555,6 +573,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     p.epilogue = kEpiForward;
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
+    if (bf3_wanted(p, pool != nullptr, false)) cfg = bf3_config();
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
@@ -635,6 +654,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
+    if (bf3_wanted(p, false, inj != nullptr)) cfg = bf3_config();
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
@@ -1031,6 +1051,7 @@ void stx_engine_destroy(stx_engine *e) {
     for (hipEvent_t ev : e->ev_tap) (void)hipEventDestroy(ev);
     if (e->ev_fwd) (void)hipEventDestroy(e->ev_fwd);
     if (e->side2) (void)hipStreamDestroy(e->side2);
+    e->marks_buf.release();
     for (Blob &b : e->blobs) {
         b.data.release();
         b.diff.release();
@@ -1387,6 +1408,15 @@ int sc_grad_prepare(stx_engine *e, const TileCall &c, TilePlan &plan) {
 // walk, the mirror copy of the loss scalars.  The tile is already in the input blob; the gradient
 // is left in its diff.  `g` non-null: the stream is being recorded into g (no timing events; the
 // content windows take their origin from g's device memory).
+constexpr int kMaxClockMarks = 8192;
+
+// stx_clock_marks: after the forward pass and at the end of the backward pass
+int clock_mark(stx_engine *e) {
+    if (!e->clock_marks || e->recording || e->marks_used >= kMaxClockMarks) return STX_OK;
+    long long *out = static_cast<long long *>(e->marks_buf.ptr) + 2 * (size_t)e->marks_used++;
+    return clock_mark_launch(e->stream, out, 2000);
+}
+
 int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingLoss &pl, TileGraph *g) {
     const std::vector<Tap> &order = plan.order;
     const std::vector<char> &needed = plan.needed;
@@ -1525,6 +1555,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     std::vector<char> observed(e->blobs.size(), 0);
     for (const Tap &tp : order) observed[tp.blob] = 1;
     STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true, &observed));
+    STX_TRY(clock_mark(e));
     if (!interleave) {
         STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
         STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
@@ -1612,6 +1643,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             STX_TRY(inject((size_t)k, written));
         }
     }
+    STX_TRY(clock_mark(e));
     if (!g) STX_TRY(end_timing(e));
     // mirror the scalars used so far (small) for the loss
     STX_HIP(hipMemcpyAsync(g ? g->scalars_host : e->scalars_host, e->arena_dev,
@@ -2274,6 +2306,27 @@ int stx_last_tile_ms(stx_engine *e, float *ms) {
     STX_TRY(e->set_device());
     STX_HIP(hipEventSynchronize(e->ev_stop));
     STX_HIP(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return STX_OK;
+}
+
+int stx_clock_marks(stx_engine *e, int on) {
+    if (!e) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    if (on) STX_TRY(e->marks_buf.ensure((size_t)kMaxClockMarks * 2 * sizeof(long long)));
+    e->clock_marks = on != 0;
+    return STX_OK;
+}
+
+int stx_clock_marks_read(stx_engine *e, double *mhz, int max_values, int *n_values) {
+    if (!e || !mhz || !n_values || max_values < 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    STX_HIP(hipStreamSynchronize(e->stream));
+    const int n = std::min(max_values, e->marks_used);
+    std::vector<long long> h((size_t)n * 2);
+    if (n) STX_HIP(hipMemcpy(h.data(), e->marks_buf.ptr, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) mhz[i] = h[2 * i + 1] > 0 ? (double)h[2 * i] / (double)h[2 * i + 1] * 100.0 : 0.0;
+    *n_values = n;
+    e->marks_used = 0;
     return STX_OK;
 }
 

@@ -387,6 +387,18 @@ class TileEngine:
         lib.call('stx_last_tile_flops', self.handle, ctypes.byref(a), ctypes.byref(b))
         return a.value, b.value
 
+    def clock_marks(self, on):
+        """While on, every sc_grad_tile records the shader clock at two points of its stream
+        (stx_clock_marks: 20-microsecond one-wave kernels)."""
+        lib.call('stx_clock_marks', self.handle, 1 if on else 0)
+
+    def clock_marks_read(self, max_values=8192):
+        """MHz of the marks recorded since the last read (synchronises this engine's stream)."""
+        mhz = (ctypes.c_double * max_values)()
+        n = ctypes.c_int(0)
+        lib.call('stx_clock_marks_read', self.handle, mhz, max_values, ctypes.byref(n))
+        return [mhz[i] for i in range(n.value)]
+
     def last_tile_ms(self):
         ms = ctypes.c_float(0)
         lib.call('stx_last_tile_ms', self.handle, ctypes.byref(ms))

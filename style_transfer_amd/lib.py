@@ -107,6 +107,8 @@ SIGNATURES = {
     'stx_op_content_terms': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, c_int_p, _vp, c_double_p],
     'stx_last_tile_ms': [_vp, c_float_p],
     'stx_last_tile_flops': [_vp, c_double_p, c_double_p],
+    'stx_clock_marks': [_vp, ctypes.c_int],
+    'stx_clock_marks_read': [_vp, c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
     'stx_profile_enable': [_vp, _i],
     'stx_profile_read': [_vp, ctypes.c_char_p, _sz, ctypes.POINTER(_sz)],
 }
