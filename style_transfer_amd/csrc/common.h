@@ -130,6 +130,7 @@ struct ConvProblem {
                                      // wino2_fuses_pool)
     float *splitk_ws = nullptr;      // scratch for split-K partial sums (optional)
     size_t splitk_ws_floats = 0;
+    const void *x_split = nullptr;   // conv_bf3.hip: the input as bf3_split_launch wrote it (optional)
 };
 
 // Tile configuration chosen for a problem; weights must be packed for the same (bm, kc).
@@ -179,6 +180,7 @@ struct WinoArgs {
     int skip_y = 0;                             // forward + fused pooling with codes: y is not stored
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
+    int vp_rows = 0, vp_tp = 0;                 // conv_bf3.hip, pre-split operand: rows / x-tiles per row of a plane
 };
 
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
@@ -196,6 +198,10 @@ size_t bf3_packed_floats(int K, int M);
 int bf3_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed);
 int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 bool bf3_usable(const ConvProblem &p);      // what the kernel takes (shape, epilogue, addressing)
+// The pre-split form: bf3_split_launch writes the transformed, three-piece operand of a whole layer
+// once (bf3_split_bytes of scratch), bf3_launch with p.x_split set reads it instead of p.x.
+size_t bf3_split_bytes(int K, int H, int W);
+int bf3_split_launch(hipStream_t s, const float *x, int K, int H, int W, void *split);
 
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
 ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16

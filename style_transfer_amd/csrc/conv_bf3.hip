@@ -79,7 +79,11 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ long long g_bf3_timing[8][8];
 #endif
 
-template <int EPI>
+// PRE: the B operand comes pre-split (bf3_split_kernel below wrote the V pieces of the whole layer
+// once, instead of every channel tile's workgroup transforming and splitting its patch again -- an
+// eighth of that vector work at 512 output channels): the staging of a chunk is then 60 16-byte-per-
+// lane loads straight into LDS (`buffer_load ... lds`, 1 KB each), dealt out over the eight waves.
+template <int EPI, bool PRE = false>
 __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 #ifdef STX_BF3_TIMING
@@ -220,16 +224,41 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
         for (int q = 0; q < 3; ++q) bq[slot][q] = *reinterpret_cast<const bf16x8 *>(vb + q * V_PIECE);
     };
 
+    // ---- PRE: piece q = (xi', piece, row pair) of a chunk's V array, 1 KB: rows y0 - 1 + 2 rp and the
+    // next one, sixteen x-tiles from x0 / 2, sixteen channels -- 512 contiguous bytes per row in the
+    // split buffer [chunk][xi][piece][row][tile][16 ch]; wave w moves pieces w, w + 8, ...
+    const unsigned plane_bytes_v = (unsigned)a.vp_rows * (unsigned)a.vp_tp * 32u;
+    const unsigned dma_voff = (unsigned)((y0 + (lane >> 5)) * a.vp_tp + (x0 >> 1)) * 32u + (unsigned)(lane & 31) * 16u;
+    auto dma = [&](int n, int buf, int chunk) __attribute__((always_inline)) {
+        const int q = wave + 8 * n;                       // < 60
+        const int comp = q / 5, rp = q - comp * 5;        // comp = xi' * 3 + piece
+        const unsigned so = (unsigned)sgpr((chunk * 12 + comp)) * plane_bytes_v +
+                            (unsigned)sgpr(rp * 2 * a.vp_tp * 32);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rx, (__attribute__((address_space(3))) void *)(ldsb + buf * V_BYTES + comp * V_PIECE + rp * 1024),
+            16, dma_voff, so, 0, 0);
+    };
+    const int n_dma = wave < 4 ? 8 : 7;                   // 60 pieces over eight waves
+
     // ---- prologue
-    x_load(0, 0);
-    if (n_units == 2) x_load(1, 0);
+    if (PRE) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) a_load(ky, 0);
-    stage_all(0, 0);
-    if (1 < n_chunks) x_load(0, 1);
-    if (n_units == 2) {
-        stage_all(1, 0);
-        if (1 < n_chunks) x_load(1, 1);
+        for (int n = 0; n < 8; ++n)
+            if (n < n_dma) dma(n, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a_load(ky, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        x_load(0, 0);
+        if (n_units == 2) x_load(1, 0);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a_load(ky, 0);
+        stage_all(0, 0);
+        if (1 < n_chunks) x_load(0, 1);
+        if (n_units == 2) {
+            stage_all(1, 0);
+            if (1 < n_chunks) x_load(1, 1);
+        }
     }
     lds_barrier();
     b_read(0, 0, 0);
@@ -247,6 +276,10 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
             const int ky = blk >> 2, j = blk & 3, slot = blk & 1;
             if (blk == 11) {
                 __builtin_amdgcn_sched_barrier(0);
+                // (PRE: this wave's pieces of the next chunk have landed -- they were requested
+                // behind block 8, after the last first use of a filter fragment in this chunk, so
+                // that the compiler's own waits for those never have to drain them)
+                if (PRE && MORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -263,7 +296,10 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
                 if (m == 5) hi[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ky][0], bq[slot][0], hi[j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 const int s = blk * 6 + m;
-                if (MORE && !(STX_BF3_SKIP & 1)) {
+                if (PRE && MORE && s >= 49 && s < 57) {
+                    if (s - 49 < 7 || wave < 4) dma(s - 49, buf ^ 1, chunk + 1);
+                }
+                if (!PRE && MORE && !(STX_BF3_SKIP & 1)) {
                     // unit 0: pieces behind slots 4, 8 (12) ...; unit 1 (waves 0, 1) in between
                     constexpr int STEP = NU == 2 ? 4 : 8;
                     if (s >= 4 && (s - 4) % STEP == 0) {
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
                         if (k < 8 * NU) piece(k >> 3, (k >> 1) & 3, k & 1, vnext, EDGE);
                     }
                 }
-                if (MORE && !(STX_BF3_SKIP & 4)) {
+                if (!PRE && MORE && !(STX_BF3_SKIP & 4)) {
                     constexpr int STEP = NU == 2 ? 4 : 8;
                     if (s == 4 + 7 * STEP + 1 && chunk + 2 < n_chunks) x_load(0, chunk + 2);
                     if (NU == 2 && s == 4 + 15 * STEP + 1 && chunk + 2 < n_chunks) x_load(1, chunk + 2);
@@ -301,7 +337,9 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
 #ifdef STX_BF3_TIMING
     const long long t_loop = clock64(), w_loop = wall_clock64();
 #endif
-    if (n_units == 2) {
+    if (PRE) {
+        main_loop(one{}, no{});
+    } else if (n_units == 2) {
         if (edge) main_loop(two{}, yes{});
         else main_loop(two{}, no{});
     } else {
@@ -399,6 +437,59 @@ __global__ __launch_bounds__(NT) void conv_bf3_kernel(WinoArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The B operand of a whole layer, transformed and split once: split[chunk][xi][piece][row][tile][16]
+// (bf16), row 0 = image row -1, rows and tiles padded with zeros to whole patches, so that the
+// convolution's workgroups fetch their V arrays without a predicate.  A thread = one (row, tile)
+// position x 8 channels: eight 16-byte loads, twelve 16-byte stores.
+static int bf3_split_rows(int H) { return ceil_div(H, PR) * PR + 2; }
+static int bf3_split_tp(int W) { return ceil_div(W, PC) * TX; }
+
+size_t bf3_split_bytes(int K, int H, int W) {
+    return (size_t)(K / KC) * 12 * bf3_split_rows(H) * bf3_split_tp(W) * 32;
+}
+
+__global__ __launch_bounds__(256) void bf3_split_kernel(const float *__restrict__ x, int K, int H, int W,
+                                                        int rows, int tp, char *__restrict__ split) {
+    const int u = blockIdx.x * 256 + threadIdx.x;         // (chunk, row, tile, channel group)
+    const int cg = u & 1, t = (u >> 1) % tp, r = ((u >> 1) / tp) % rows, chunk = (u >> 1) / (tp * rows);
+    if (chunk >= K / KC) return;
+    const int yy = r - 1, xx = 2 * t - 1;
+    const size_t HW = (size_t)H * W;
+    f32x4 d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float *px = x + (size_t)(chunk * KC + cg * 8 + i) * HW + (size_t)yy * W;
+        const bool row = (unsigned)yy < (unsigned)H;
+        d[i].x = row && xx >= 0 && xx < W ? px[xx] : 0.f;
+        d[i].y = row && xx + 1 < W ? px[xx + 1] : 0.f;
+        d[i].z = row && xx + 2 < W ? px[xx + 2] : 0.f;
+        d[i].w = row && xx + 3 < W ? px[xx + 3] : 0.f;
+    }
+    const size_t plane = (size_t)rows * tp * 32;
+    char *dst = split + (size_t)chunk * 12 * plane + ((size_t)r * tp + t) * 32 + cg * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = c == 0 ? d[i].x - d[i].z : c == 1 ? d[i].y + d[i].z : c == 2 ? d[i].z - d[i].y : d[i].y - d[i].w;
+        bf16x8 q[3];
+        split3_bf16(v, q[0], q[1], q[2]);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<bf16x8 *>(dst + (c * 3 + n) * plane) = q[n];
+    }
+}
+
+int bf3_split_launch(hipStream_t s, const float *x, int K, int H, int W, void *split) {
+    const int rows = bf3_split_rows(H), tp = bf3_split_tp(W);
+    const size_t units = (size_t)(K / KC) * rows * tp * 2;
+    bf3_split_kernel<<<(unsigned)((units + 255) / 256), 256, 0, s>>>(x, K, H, W, rows, tp,
+                                                                   static_cast<char *>(split));
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 size_t bf3_packed_floats(int K, int M) {
     return (size_t)ceil_div(M, BM) * ceil_div(K, KC) * (U_CHUNK / 4);
 }
@@ -475,9 +566,9 @@ bool bf3_usable(const ConvProblem &p) {
     return xb < 2147483648.0 && yb < 2147483648.0 && wb < 2147483648.0;
 }
 
-template <int EPI>
+template <int EPI, bool PRE>
 static int bf3_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_bf3_kernel<EPI>;
+    auto kern = conv_bf3_kernel<EPI, PRE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
@@ -519,9 +610,25 @@ int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int k
     a.x_bytes = (int)(4.0 * p.K * (double)p.H * p.W);
     a.w_bytes = (int)(4 * bf3_packed_floats(p.K, p.M));
     const int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
+    if (p.x_split) {
+        const size_t bytes = bf3_split_bytes(p.K, p.H, p.W);
+        if (bytes >= 2147483648ull) {
+            set_error("bf3_launch: the split operand of a %d x %d x %d blob exceeds 2 GiB", p.K, p.H, p.W);
+            return STX_ERR_UNSUPPORTED;
+        }
+        a.x = static_cast<const float *>(p.x_split);
+        a.x_bytes = (int)bytes;
+        a.vp_rows = bf3_split_rows(p.H);
+        a.vp_tp = bf3_split_tp(p.W);
+        switch (p.epilogue) {
+            case kEpiForward: return bf3_launch_epi<kEpiForward, true>(s, a, n_wg);
+            case kEpiDgrad: return bf3_launch_epi<kEpiDgrad, true>(s, a, n_wg);
+        }
+        return STX_ERR_UNSUPPORTED;
+    }
     switch (p.epilogue) {
-        case kEpiForward: return bf3_launch_epi<kEpiForward>(s, a, n_wg);
-        case kEpiDgrad: return bf3_launch_epi<kEpiDgrad>(s, a, n_wg);
+        case kEpiForward: return bf3_launch_epi<kEpiForward, false>(s, a, n_wg);
+        case kEpiDgrad: return bf3_launch_epi<kEpiDgrad, false>(s, a, n_wg);
     }
     return STX_ERR_UNSUPPORTED;
 }
