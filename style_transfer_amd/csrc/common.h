@@ -204,7 +204,7 @@ size_t bf3_split_bytes(int K, int H, int W);
 int bf3_split_launch(hipStream_t s, const float *x, int K, int H, int W, void *split);
 
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
-ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16
+ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16, 2: 8 x 32
 int wino2_pick_geometry(int H, int W);
 size_t wino2_packed_floats(int K, int M);
 int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,

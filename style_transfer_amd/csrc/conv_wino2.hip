@@ -57,7 +57,7 @@ namespace {
 
 constexpr int KC = 8, BM = 64, NT = 512;
 // Pixel patch of a workgroup = 64 tiles.  TXW = tiles per tile row within a wave's 32: 32 -> 4 rows x
-// 64 columns (long row segments for loads and stores), 8 -> 16 x 16 pixels (planes whose width is
+// 64 columns (long row segments for loads and stores), 16 -> 8 x 32 pixels, 8 -> 16 x 16 pixels (planes whose width is
 // not near a multiple of 64, e.g. the 91 x 91 / 46 x 46 planes of a 724-pixel tile).
 template <int TXW>
 struct Geo {
@@ -746,8 +746,8 @@ ConvConfig wino2_config(int geometry) {
     c.id = 200 + geometry;            // ids >= 200 mark the 2-D Winograd configurations
     c.bm = BM;
     c.kc = KC;
-    c.pr = geometry ? Geo<8>::PR : Geo<32>::PR;
-    c.pc = geometry ? Geo<8>::PC : Geo<32>::PC;
+    c.pr = geometry == 1 ? Geo<8>::PR : geometry == 2 ? Geo<16>::PR : Geo<32>::PR;
+    c.pc = geometry == 1 ? Geo<8>::PC : geometry == 2 ? Geo<16>::PC : Geo<32>::PC;
     c.threads = NT;
     c.lds_bytes = kLdsBytes;
     return c;
@@ -760,8 +760,16 @@ ConvConfig wino2_config(int geometry) {
 // compute every output with the same arithmetic in the same order: the choice never changes
 // a result.
 int wino2_pick_geometry(int H, int W) {
-    (void)H;
-    return W <= 40 ? 1 : 0;
+    if (W <= 40) return 1;
+    // 8 x 32 patches where they need at least a tenth fewer workgroups than 4 x 64 ones (the 91 x 91
+    // planes of a 724-pixel tile: 36 instead of 46 per channel tile) -- the third geometry the
+    // four-wave kernel has had since round 2, now also for the layers only this kernel runs (the
+    // loss-injecting ones).  STX_WINO2_GEO8X32=0 keeps the two-geometry rule.
+    const char *env = getenv("STX_WINO2_GEO8X32");
+    if (env && atoi(env) == 0) return 0;
+    const long wide = (long)ceil_div(H, Geo<32>::PR) * ceil_div(W, Geo<32>::PC);
+    const long mid = (long)ceil_div(H, Geo<16>::PR) * ceil_div(W, Geo<16>::PC);
+    return mid * 10 <= wide * 9 ? 2 : 0;
 }
 
 // K split of a launch.  One workgroup per CU and ~6 us of prologue + epilogue per workgroup make
@@ -940,14 +948,17 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
 #define STX_W2_CASE(E)                                                                            \
     case E:                                                                                       \
         if (big && E != kEpiPartial)                                                              \
-            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8, true>(s, a, n_wg))                    \
-                                  : (wino2_launch_epi<E, 32, true>(s, a, n_wg)));                 \
+            STX_TRY(cfg.id == 201   ? (wino2_launch_epi<E, 8, true>(s, a, n_wg))                  \
+                    : cfg.id == 202 ? (wino2_launch_epi<E, 16, true>(s, a, n_wg))                 \
+                                    : (wino2_launch_epi<E, 32, true>(s, a, n_wg)));               \
         else if (mk && (E == kEpiForward || E == kEpiDgrad || E == kEpiDgradInject))              \
-            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8, false, true>(s, a, n_wg))             \
-                                  : (wino2_launch_epi<E, 32, false, true>(s, a, n_wg)));          \
+            STX_TRY(cfg.id == 201   ? (wino2_launch_epi<E, 8, false, true>(s, a, n_wg))           \
+                    : cfg.id == 202 ? (wino2_launch_epi<E, 16, false, true>(s, a, n_wg))          \
+                                    : (wino2_launch_epi<E, 32, false, true>(s, a, n_wg)));        \
         else                                                                                      \
-            STX_TRY(cfg.id == 201 ? (wino2_launch_epi<E, 8>(s, a, n_wg))                          \
-                                  : (wino2_launch_epi<E, 32>(s, a, n_wg)));                       \
+            STX_TRY(cfg.id == 201   ? (wino2_launch_epi<E, 8>(s, a, n_wg))                        \
+                    : cfg.id == 202 ? (wino2_launch_epi<E, 16>(s, a, n_wg))                       \
+                                    : (wino2_launch_epi<E, 32>(s, a, n_wg)));                     \
         break;
     switch (epi) {
         STX_W2_CASE(kEpiForward)

@@ -428,6 +428,7 @@ static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, Co
         if (!strcmp(algo, "wino2")) { *out = wino2_config(wino2_pick_geometry(H, W)); return true; }
         if (!strcmp(algo, "wino2a")) { *out = wino2_config(0); return true; }   // one geometry only
         if (!strcmp(algo, "wino2b")) { *out = wino2_config(1); return true; }
+        if (!strcmp(algo, "wino2c")) { *out = wino2_config(2); return true; }
         if (!strcmp(algo, "wino4")) { *out = wino4_config(wino4_pick_geometry(K, M, H, W)); return true; }
         if (!strcmp(algo, "wino4old")) { *out = wino4_config(wino2_pick_geometry(H, W)); return true; }
         if (!strcmp(algo, "wino4a")) { *out = wino4_config(0); return true; }
