@@ -25,7 +25,15 @@ constexpr int kChunk = 3 * kM * 64;            // bytes: [piece][row][32 k bf16]
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 }  // namespace lean
 
+#ifndef STX_LEAN_PREFETCH
+#define STX_LEAN_PREFETCH 0   // 1: the F fragment of the next step is requested before this step's MFMAs
+#endif                       // (8 more registers: no longer fits beside a convolution workgroup)
+
+#if STX_LEAN_PREFETCH
+__global__ __launch_bounds__(256) void symm_lean_kernel(
+#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void symm_lean_kernel(
+#endif
     const float *__restrict__ F, const unsigned short *__restrict__ Dp, float *__restrict__ S,
     float *__restrict__ partials, int C, int Cp, int HW, unsigned f_bytes, int m_tiles) {
     using namespace lean;
@@ -74,20 +82,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void symm
     for (int i = 0; i < 4; ++i) acc[i] = f32x4a{0.f, 0.f, 0.f, 0.f};
 
     d_dma(0, 0);
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int buf = chunk & 1;
-        // F fragment of this step: channels 32 chunk + 8 g .. + 7 of pixel px
-        float raw[8];
+    float raw[8];
+    auto f_load = [&](int chunk) __attribute__((always_inline)) {
+        // F fragment of a step: channels 32 chunk + 8 g .. + 7 of pixel px
         const int k0 = __builtin_amdgcn_readfirstlane(chunk * kK);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             raw[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                    rf, fvoff, (unsigned)min(k0 + e, C) * HW4, 0));
+    };
+    if (STX_LEAN_PREFETCH) f_load(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (!STX_LEAN_PREFETCH) f_load(chunk);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the D chunk and the fragment)
         __syncthreads();                                    // chunk `chunk` is in LDS; the other buffer is free
         if (chunk + 1 < n_chunks) d_dma(chunk + 1, buf ^ 1);
         bf16x8 pb[3];
         split3_bf16(raw, pb[0], pb[1], pb[2]);
+        if (STX_LEAN_PREFETCH && chunk + 1 < n_chunks) f_load(chunk + 1);
         const unsigned char *base = lds + buf * kChunk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
