@@ -8,32 +8,42 @@
 One step = one optimizer iteration of the reference's step loop (style_transfer.py:771-806) at the
 top scale of the configuration BASELINE.json's metric is quoted on ("VGG-19 --size 2048 --tile-size
 1024, Adam"): draw the seam-suppression shift, cut the four 1024 x 1024 tiles, per-tile VGG-19
-forward + Gram/content losses + backward (stx_sc_grad_tile; the four tiles run concurrently on four
-HIP streams of the GPU), stitch, TV + p-norm regularizers, fused Adam step with iterate averaging,
-step statistics.  Everything is resident in HBM when the timed region starts.  Synthetic data:
-seeded He-initialised VGG-19 weights, seeded low-pass-noise content and style pictures (no network).
+forward + Gram/content losses + backward (stx_sc_grad_tile), stitch, TV + p-norm regularizers,
+fused Adam step with iterate averaging, step statistics.  Everything is resident in HBM when the
+timed region starts.  Synthetic data: seeded He-initialised VGG-19 weights, seeded low-pass-noise
+content and style pictures (no network).
 
-At N = 1 the step loop runs through TileFarm, the product's own driver.  N > 1 is weak scaling:
-every rank evaluates four 1024 x 1024 tiles per step and the image grows with N (2048 x 4096,
-4096 x 4096 -- config 4's top scale -- and 4096 x 8192 at N = 2, 4, 8); rank 0 owns the image and
-the optimizer, tiles go out and gradients come back as batched point-to-point transfers over RCCL,
-there is no collective on the data path.  value = tile-iterations per second of the whole job.
-north_star's layout -- ONE host process driving all N GPUs through TileFarm (tiles and gradients
-as xGMI peer copies ordered by events, no host wait inside a step) -- is timed on the same image
-and step loop after the ranks have finished, and reported as the `farm` sub-record.
+`value` is ALWAYS that workload -- the fixed 2048 x 2048 image, four tiles per step -- so for
+N > 1 it is STRONG scaling, exactly what the metric names ("VGG-19 2048px/1024-tile, 1/2/4/8
+MI355X"): 2 / 1 / 1 tiles per GPU at N = 2 / 4 / 8 (at N = 8 four GPUs have no tile and the line
+says so).  At N = 1 the step loop runs through TileFarm, the product's own driver (four HIP
+streams on the GPU).  At N > 1 it runs one process per GPU as the benchmark contract prescribes:
+rank 0 owns the image and the optimizer, tiles go out and gradients come back as batched
+point-to-point transfers over RCCL, no collective on the data path.
+
+Sub-records at N > 1 (each also carries `bit_identical`: step 1 of its warm-up is evaluated on the
+N GPUs and again on GPU 0 alone -- tiles are independent, so loss and gradient must agree bit for
+bit; a run on real xGMI thereby validates the peer copies / RCCL transfers by itself):
+  farm          north_star's layout on the same 2048 x 2048 workload: ONE host process driving
+                the N GPUs through TileFarm (tiles and gradients as xGMI peer copies ordered by
+                events, no host wait inside a step);
+  config4       BASELINE config 4's top scale: 4096 x 4096, 16 tiles of 1024 x 1024, L-BFGS,
+                through TileFarm over the N GPUs;
+  weak          the round-1..3 headline kept for continuity: four tiles per GPU, the image grows
+                with N (2048 x 4096, 4096 x 4096, 4096 x 8192), one process per GPU.
 
 The line also carries
   roofline      the time the kernels' own instructions need on the matrix pipe, in fp32-MFMA FLOP,
-                for the four tile-iterations of one GPU (convolutions through Winograd F(2x2,3x3)
-                issue 4/9 of a direct convolution's MFMAs; Gram and SYMM run as six bf16 MFMAs per
-                16 k and are counted at the 0.375 of their fp32 pipe time that this occupies) over
-                the GPU time of that concurrent group of stx_sc_grad_tile calls -- HIP events on
-                each engine's own stream inside the timed region, the longest of the four spans --
-                against the fp32 MFMA peak, so that frac <= 1 by construction; `bound_ms` is the
-                time the same work takes at that peak; `frac_round2_accounting` counts Gram and
-                SYMM in full, as round 2 did.  The SURVEY 8d figure (1 514 240 FLOP per tile pixel,
-                every convolution counted as a direct one) is kept beside it as
-                achieved_direct_equiv;
+                for the concurrent tile-iterations of one GPU (convolutions through Winograd
+                F(2x2,3x3) issue 4/9 of a direct convolution's MFMAs; Gram and SYMM run as six bf16
+                MFMAs per 16 k and are counted at the 0.375 of their fp32 pipe time that this
+                occupies) over the GPU time of that concurrent group of stx_sc_grad_tile calls --
+                HIP events on each engine's own stream inside the timed region, the longest of the
+                spans -- against the fp32 MFMA peak, so that frac <= 1 by construction;
+                `frac_driver_clock` divides the same work by the wall-clock ms_per_step instead;
+                `bound_ms` is the time the same work takes at that peak.  The SURVEY 8d figure
+                (1 514 240 FLOP per tile pixel, every convolution counted as a direct one) is kept
+                beside it as achieved_direct_equiv;
   steady        the same step loop run for at least 5 s after the timed region;
   wall_clock_s  the WHOLE `--size 2048 --tile-size 1024` command-line run (7 pyramid scales,
                 800 iterations, 1400 tile-iterations, preprocessing and PNG output included) on
@@ -57,8 +67,10 @@ TILE = 1024
 FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
 NOMINAL_CLOCK_MHZ = 2400.0
-TILES_PER_GPU = 4
-GRIDS = {1: (2, 2), 2: (2, 4), 4: (4, 4), 8: (4, 8)}      # tile grid of the image per world size
+STREAMS_PER_GPU = 4                    # engines (HIP streams) a GPU runs its tiles of a step on
+STRONG_GRID = (2, 2)                   # BASELINE's metric: --size 2048 --tile-size 1024
+CONFIG4_GRID = (4, 4)                  # BASELINE config 4's top scale: --size 4096, 16 tiles
+WEAK_GRIDS = {1: (2, 2), 2: (2, 4), 4: (4, 4), 8: (4, 8)}    # four tiles per GPU
 CONTENT_LAYERS = ['conv4_2']
 STYLE_LAYERS = ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
 MEAN = (103.939, 116.779, 123.68)
@@ -74,21 +86,24 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
-TRAFFIC_PROFILE = 'profiles/r03_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE = 'profiles/r04_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE_FALLBACK = 'profiles/r03_hbm_traffic_pmc.json'
 
 
-def measured_traffic():
+def measured_traffic(tiles_per_launch):
     """(bytes per launch group, source file): HBM bytes from the PMC passes over THIS script
     (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per
     the gfx950 calibration on the Adam kernel -- tools/pmc_traffic.py).  Counters cannot be
     collected inside a timed run, so the figure is a replay of the committed profile of this
     build state and the line names the file; (None, None) if it is missing."""
-    try:
-        with open(os.path.join(REPO, TRAFFIC_PROFILE)) as f:
-            # measured per tile-iteration; one launch group = 4 of them
-            return float(json.load(f)['hbm_bytes_per_tile_iteration']) * TILES_PER_GPU, TRAFFIC_PROFILE
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for name in (TRAFFIC_PROFILE, TRAFFIC_PROFILE_FALLBACK):
+        try:
+            with open(os.path.join(REPO, name)) as f:
+                # measured per tile-iteration
+                return float(json.load(f)['hbm_bytes_per_tile_iteration']) * tiles_per_launch, name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(net):
@@ -118,48 +133,67 @@ def cpu_baseline(net):
                       % (reps, size, size, dt)}
 
 
+CONTENT_WEIGHT = {'conv4_2': 0.05}
+STYLE_WEIGHT = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
+
+
+def start_image(H, W):
+    """The reference's start image: uniform noise minus the mean (style_transfer.py:889)."""
+    rng = np.random.RandomState(0)
+    return rng.uniform(0, 255, (3, H, W)).astype(np.float32) - np.float32(MEAN).reshape(3, 1, 1)
+
+
+def draw_roll(rng, H, W):
+    """The iteration's seam-suppression shift (style_transfer.py:777-779)."""
+    return (np.int32(rng.uniform(-0.5, 0.5, size=2) * (H, W)) // 8) * 8
+
+
+def targets_on(farm, H, W):
+    """Style Grams of a 1024 x 1024 picture and the content map of the H x W picture, computed on
+    the farm's master GPU."""
+    style_feats = farm.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS, TILE,
+                                               passes=1)
+    styles = [{l: farm.master.gram_matrix(f) for l, f in style_feats.items()}]
+    contents = [farm.prepare_features_device(smooth_picture(8, H, W), CONTENT_LAYERS, TILE, passes=1)]
+    return contents, styles
+
+
 class FarmJob:
     """The benchmark's step loop on a TileFarm over `devices` (one host process): image of
-    rows x cols tiles of 1024 x 1024, targets computed on the master GPU, Adam."""
+    rows x cols tiles of 1024 x 1024, targets computed on the master GPU, Adam (or L-BFGS)."""
 
-    def __init__(self, net, weights, devices, rows, cols):
+    def __init__(self, net, weights, devices, rows, cols, optimizer='adam', force_staging=None):
         from style_transfer_amd import image_ops
         from style_transfer_amd.farm import TileFarm
-        from style_transfer_amd.optimizers import AdamOptimizer
+        from style_transfer_amd.optimizers import AdamOptimizer, LBFGSOptimizer
         self.image_ops = image_ops
+        self.net, self.weights = net, weights
         self.H, self.W = rows * TILE, cols * TILE
         self.farm = TileFarm(net, list(devices), weights, verbose=False,
-                             streams_per_device=TILES_PER_GPU)
+                             streams_per_device=STREAMS_PER_GPU, force_staging=force_staging)
         eng = self.eng = self.farm.master
-        style_feats = self.farm.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS,
-                                                        TILE, passes=1)
-        styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
-        contents = [self.farm.prepare_features_device(smooth_picture(8, self.H, self.W),
-                                                      CONTENT_LAYERS, TILE, passes=1)]
-        self.farm.set_contents_and_styles(contents, styles)
-        self.content_weight = {'conv4_2': 0.05}
-        self.style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
-        rng = np.random.RandomState(0)
-        # the reference's start image: uniform noise minus the mean (style_transfer.py:889)
-        self.img = eng.to_device(rng.uniform(0, 255, (3, self.H, self.W)).astype(np.float32) -
-                                 np.float32(MEAN).reshape(3, 1, 1))
+        self.farm.set_contents_and_styles(*targets_on(self.farm, self.H, self.W))
+        self.img = eng.to_device(start_image(self.H, self.W))
         self.grad = eng.empty((3, self.H, self.W))
         self.old = eng.empty((3, self.H, self.W)).copy_from(self.img)
         self.rng = np.random.RandomState(0)
-        self.opt = AdamOptimizer(eng, self.img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
+        if optimizer == 'adam':
+            self.opt = AdamOptimizer(eng, self.img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
+        else:       # the command line's -o lbfgs (style_transfer.py:896-897)
+            self.opt = LBFGSOptimizer(eng, self.img)
         self.group_ms = []
         self.clock = None
         self.tiles_per_step = rows * cols
+        self.tiles_per_gpu = -(-self.tiles_per_step // len(set(devices)))
 
     def step(self):
         """One iteration of the reference's step loop (style_transfer.py:771-815); one host
         synchronisation, for the step statistics."""
-        xy = np.int32(self.rng.uniform(-0.5, 0.5, size=2) * (self.H, self.W)) // 8
-        roll = xy * 8
+        roll = draw_roll(self.rng, self.H, self.W)
 
         def opfunc(params):
             loss = self.farm.eval_sc_grad(params, self.grad, roll, CONTENT_LAYERS, STYLE_LAYERS, {},
-                                          self.content_weight, self.style_weight, TILE, lazy=True)
+                                          CONTENT_WEIGHT, STYLE_WEIGHT, TILE, lazy=True)
             loss.add(self.image_ops.regularizers(self.eng, params, self.grad, MEAN, 5.0, 2.0, 2.0,
                                                  6.0), self.eng)
             return loss, self.grad
@@ -183,47 +217,78 @@ class FarmJob:
         engines = self.farm.engines[:self.tiles_per_step] if clock_marks else []
         for e in engines:
             e.clock_marks(True)
+        evals0 = self.farm.tile_evals
         t0 = time.perf_counter()
         loss = None
         for _ in range(steps):
             loss = self.step()
         self.fence()
         elapsed = time.perf_counter() - t0
+        self.timed_tile_evals = self.farm.tile_evals - evals0
         if clock_marks:
             self.clock = clock_summary(engines)
         return elapsed, loss
 
-    def graph_counters(self):
-        from style_transfer_amd import lib
-        return {'captures': sum(e.query(lib.Q_GRAPH_CAPTURES) for e in self.farm.engines),
-                'replays': sum(e.query(lib.Q_GRAPH_REPLAYS) for e in self.farm.engines),
-                'eager': sum(e.query(lib.Q_EAGER_TILES) for e in self.farm.engines)}
+    def bit_identical(self):
+        """Evaluates ONE step's loss and gradient on this farm (all its GPUs) and on a one-GPU farm
+        on the master's device: tiles are independent, so both must be bit-identical.  Over real
+        xGMI this validates the peer copies and the event ordering by itself."""
+        from style_transfer_amd.farm import TileFarm
+        roll = draw_roll(np.random.RandomState(123), self.H, self.W)
+        args = (roll, CONTENT_LAYERS, STYLE_LAYERS, {}, CONTENT_WEIGHT, STYLE_WEIGHT, TILE)
+        loss_n = self.farm.eval_sc_grad(self.img, self.grad, *args)
+        grad_n = self.grad.get()
+        solo = TileFarm(self.net, [self.eng.device], verbose=False, engines=[self.eng])
+        ref = self.eng.empty((3, self.H, self.W))
+        loss_1 = solo.eval_sc_grad(self.img, ref, *args)
+        same = bool(loss_n == loss_1 and np.array_equal(grad_n, ref.get()))
+        ref.free()
+        solo.close()
+        return same
 
     def close(self):
         self.farm.close()
 
 
-def farm_leg(devices, rows, cols, steps, warmup):
-    """The benchmark's step loop through TileFarm over `devices` in THIS process; the `farm`
-    sub-record."""
+def farm_leg(devices, rows, cols, steps, warmup, optimizer='adam', force_staging=None, check=True):
+    """The benchmark's step loop through TileFarm over `devices` in THIS process: the `farm` and
+    `config4` sub-records."""
+    from style_transfer_amd import lib
     from style_transfer_amd.netspec import builtin_net
     from style_transfer_amd.weights import synthetic_weights
     net = builtin_net('vgg19')
-    job = FarmJob(net, synthetic_weights(net, 0), devices, rows, cols)
+    job = FarmJob(net, synthetic_weights(net, 0), devices, rows, cols, optimizer, force_staging)
+    same = job.bit_identical() if check else None
     elapsed, loss = job.timed(steps, warmup)
-    record = {'layout': 'one host process, TileFarm over %d GPUs (xGMI peer copies, event-ordered, '
-                        'no host wait inside a step)' % len(devices),
-              'value': job.tiles_per_step * steps / elapsed, 'unit': 'tile-iterations/s',
+    n_dev = len(set(devices))
+    busy = min(n_dev, job.tiles_per_step)
+    record = {'layout': 'one host process, TileFarm over %d GPU(s) (xGMI peer copies, event-ordered, '
+                        'no host wait inside a step)' % n_dev,
+              'workload': 'VGG-19 %dx%d image, %d tiles of %dx%d per step, -o %s; %d tile(s) per busy GPU, '
+                          '%d GPU(s) without a tile' % (job.W, job.H, job.tiles_per_step, TILE, TILE,
+                                                         optimizer, job.tiles_per_gpu, n_dev - busy),
+              'scaling': 'strong', 'n_gpus': n_dev, 'idle_gpus': n_dev - busy,
+              'value': job.timed_tile_evals / elapsed, 'unit': 'tile-iterations/s',
               'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'final_loss': loss,
-              'avg_launch_ms': float(np.mean(job.group_ms)), 'graphs': job.graph_counters()}
+              'avg_launch_ms': float(np.mean(job.group_ms)),
+              'tile_evals': int(sum(e.query(lib.Q_TILE_EVALS) for e in job.farm.engines)),
+              'peers_without_access': int(sum(e.query(lib.Q_PEERS_WITHOUT_ACCESS)
+                                              for e in job.farm.primaries())),
+              'bit_identical': same}
     job.close()
     return record
 
 
-def farm_leg_in_child(world, rows, cols, steps, warmup, timeout=300):
+def farm_leg_in_child(devices, rows, cols, steps, warmup, optimizer='adam', force_staging=False,
+                      timeout=420):
+    """farm_leg in a child process with a deadline: a fault on a never-exercised peer path must
+    not take the benchmark line with it."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--farm-leg', str(world), '--debug-grid',
-           '%dx%d' % (rows, cols), '--steps', str(steps), '--warmup', str(warmup)]
+    cmd = [sys.executable, os.path.abspath(__file__), '--farm-leg', ','.join(str(d) for d in devices),
+           '--debug-grid', '%dx%d' % (rows, cols), '--steps', str(steps), '--warmup', str(warmup),
+           '--farm-optimizer', optimizer]
+    if force_staging:
+        cmd.append('--farm-force-staging')
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK')}
     try:
@@ -312,34 +377,37 @@ def add_clock(roofline, clock):
                      'frac_at_clock': roofline['achieved'] / peak_at_clock})
 
 
-def roofline_record(eng, avg_group_ms):
-    """Matrix-pipe work of one GPU's four concurrent tile evaluations over their HIP-event span,
+def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
+    """Matrix-pipe work of one GPU's concurrent tile evaluations over their HIP-event span,
     against the fp32 MFMA peak.  Every term is the time the kernels' own instructions need on the
     matrix pipe, expressed in fp32-MFMA FLOP: Winograd convolutions issue 4/9 (2-D) or 2/3 (1-D) of
     a direct convolution's fp32 MFMAs; Gram and SYMM issue six bf16 MFMAs per 16 k, which occupy
     the pipe for 0.375 of the time their fp32 form would -- so frac <= 1 by construction."""
-    flop = FLOP_PER_TILE_PIXEL * TILE * TILE * TILES_PER_GPU
+    flop = FLOP_PER_TILE_PIXEL * TILE * TILE * tiles_per_gpu
     direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
     conv_alg, conv_issued = eng.last_tile_flops()
     terms = GRAM_SYMM_FLOP_PER_TILE_PIXEL * TILE * TILE
     bf16_terms = os.environ.get('STX_GRAM') != 'fp32' and os.environ.get('STX_SYMM') != 'fp32'
-    per_tile = flop / TILES_PER_GPU - conv_alg - terms + conv_issued
-    issued_r02 = (per_tile + terms) * TILES_PER_GPU            # round-2 accounting: terms at the fp32 rate
-    issued = (per_tile + terms * (BF16X3_PIPE_TIME if bf16_terms else 1.0)) * TILES_PER_GPU
+    per_tile = flop / tiles_per_gpu - conv_alg - terms + conv_issued
+    issued_r02 = (per_tile + terms) * tiles_per_gpu            # round-2 accounting: terms at the fp32 rate
+    issued = (per_tile + terms * (BF16X3_PIPE_TIME if bf16_terms else 1.0)) * tiles_per_gpu
     issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
     bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
-    traffic, traffic_src = measured_traffic()
+    traffic, traffic_src = measured_traffic(tiles_per_gpu)
     return {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
+            # the same work over the wall-clock step (cut, stitch, regularizers, Adam, statistics
+            # and the host's share included): what the driver's own clock sees
+            'frac_driver_clock': issued / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             'frac_round2_accounting': issued_r02 / (avg_group_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / TILES_PER_GPU,
+            'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / tiles_per_gpu,
             'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
             'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_wino2_kernel<0|1|3,32> '
                       '(3x3 layers forward / backward / loss-injecting backward; 80 %% of the time), '
                       'conv_mfma_kernel (first layer), conv3x3_m4_kernel (backward into the image), '
                       'gram_partial_bf3_kernel / symm_bf3_kernel (bf16 MFMA, three-piece split)'
-                      % TILES_PER_GPU,
+                      % tiles_per_gpu,
             'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
             'achieved_direct_equiv': direct_equiv,
             'flop_direct_equiv_per_launch': flop,
@@ -347,7 +415,8 @@ def roofline_record(eng, avg_group_ms):
                     'F(2x2,3x3) convolutions issue 4/9 of a direct convolution; Gram and SYMM run as '
                     'six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 form and are '
                     'counted at that) over the HIP-event time of the launch group, against the fp32 '
-                    'MFMA peak at 2.4 GHz; clock_mhz is the shader clock during the second, longer measurement '
+                    'MFMA peak at 2.4 GHz; frac_driver_clock = the same work over the wall-clock '
+                    'ms_per_step; clock_mhz is the shader clock during the second, longer measurement '
                     '(`steady`; stx_clock_marks: two 20-microsecond readings of core cycles against the '
                     '100 MHz counter per tile evaluation, each good to about 3 %; the median), peak_at_clock '
                     'the fp32 MFMA peak at min(that clock, 2.4 GHz) and frac_at_clock = achieved / '
@@ -368,19 +437,24 @@ def main():
     ap.add_argument('--no-wall-clock', action='store_true',
                     help='skip the whole-run wall-clock leg (about 10 s)')
     ap.add_argument('--no-farm-leg', action='store_true',
-                    help='N > 1: skip the single-host-process (TileFarm) measurement')
-    ap.add_argument('--farm-leg', type=int, default=0, metavar='N',
-                    help='internal: only the single-host-process (TileFarm) step loop over GPUs 0..N-1 '
-                         'with the tile grid of --debug-grid; prints the `farm` sub-record')
+                    help='N > 1: skip the single-host-process (TileFarm) sub-records `farm` and `config4`')
+    ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the weak-scaling sub-record')
+    ap.add_argument('--farm-leg', default='', metavar='D0,D1,...',
+                    help='internal: only the single-host-process (TileFarm) step loop over these devices '
+                         'with the tile grid of --debug-grid; prints the sub-record')
+    ap.add_argument('--farm-optimizer', default='adam', choices=['adam', 'lbfgs'])
+    ap.add_argument('--farm-force-staging', action='store_true')
     ap.add_argument('--steady-seconds', type=float, default=5.0)
     ap.add_argument('--debug-grid', default=None,
-                    help='RxC tile grid instead of the one for --gpus (tests only: lets a single '
+                    help='RxC tile grid instead of the 2x2 of the metric (tests only: lets a single '
                          'process evaluate the image of a larger job)')
     opts = ap.parse_args()
 
     if opts.farm_leg:
         r, c = (int(v) for v in opts.debug_grid.split('x'))
-        print(json.dumps(farm_leg(list(range(opts.farm_leg)), r, c, opts.steps, opts.warmup)), flush=True)
+        devices = [int(d) for d in opts.farm_leg.split(',')]
+        print(json.dumps(farm_leg(devices, r, c, opts.steps, opts.warmup, opts.farm_optimizer,
+                                  opts.farm_force_staging or None)), flush=True)
         return
     import torch                                       # first: one HIP runtime for both libraries
     rank = int(os.environ.get('RANK', '0'))
@@ -391,12 +465,13 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
                      '(one process per GPU)' % opts.gpus)
         sys.exit('WORLD_SIZE=%d does not match --gpus %d' % (world, opts.gpus))
-    if opts.gpus not in GRIDS:
-        sys.exit('--gpus must be one of %s' % sorted(GRIDS))
+    if opts.gpus not in WEAK_GRIDS:
+        sys.exit('--gpus must be one of %s' % sorted(WEAK_GRIDS))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an AMD GPU (no CPU path exists)')
     # STX_BENCH_DEBUG_ONE_GPU=1 (debugging the N > 1 protocol on a 1-GPU box only): every rank
-    # uses GPU 0 and tiles travel over gloo through host memory.  Never a benchmark number.
+    # uses GPU 0, tiles travel over gloo through host memory, and the TileFarm sub-records list
+    # GPU 0 N times with the cross-GPU staging leg forced.  Never a benchmark number.
     debug_one_gpu = os.environ.get('STX_BENCH_DEBUG_ONE_GPU') == '1'
     if debug_one_gpu:
         local_rank = 0
@@ -406,7 +481,7 @@ def main():
     from style_transfer_amd.netspec import builtin_net
     from style_transfer_amd.weights import synthetic_weights
     net = builtin_net('vgg19')
-    rows, cols = GRIDS[world] if not opts.debug_grid else \
+    rows, cols = STRONG_GRID if not opts.debug_grid else \
         tuple(int(v) for v in opts.debug_grid.split('x'))
 
     if world == 1:
@@ -415,14 +490,16 @@ def main():
         line = bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_one_gpu)
     if rank != 0:
         return
-    devices = list(range(world)) if not debug_one_gpu else [0]
-    if world > 1 and not opts.no_farm_leg and not debug_one_gpu:
-        # north_star's layout on the same image and step loop: one host process, N GPUs.  The
-        # other ranks have left (their process group is gone, their engines are closed).  A child
-        # process with a deadline: a fault on a never-exercised peer path must not take the
-        # benchmark line with it.
-        line['farm'] = farm_leg_in_child(world, rows, cols, opts.steps, opts.warmup)
-    if not opts.no_wall_clock and not debug_one_gpu:
+    devices = list(range(world)) if not debug_one_gpu else [0] * world
+    if world > 1 and not opts.no_farm_leg:
+        # north_star's layout: one host process, N GPUs.  The other ranks have left (their process
+        # group is gone, their engines are closed).
+        line['farm'] = farm_leg_in_child(devices, rows, cols, opts.steps, opts.warmup,
+                                         force_staging=debug_one_gpu)
+        line['config4'] = farm_leg_in_child(devices, CONFIG4_GRID[0], CONFIG4_GRID[1],
+                                            max(2, opts.steps // 2), min(opts.warmup, 2), 'lbfgs',
+                                            force_staging=debug_one_gpu)
+    if not opts.no_wall_clock:
         # the whole command-line run on this job's GPUs, one host process
         try:
             line.update(whole_run_wall_clock(devices))
@@ -434,29 +511,35 @@ def main():
     print(json.dumps(line), flush=True)
 
 
-def base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms):
+def base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms, scaling='strong'):
     H, W = rows * TILE, cols * TILE
     tiles_per_step = rows * cols
+    busy = min(world, tiles_per_step)
+    tiles_per_gpu = -(-tiles_per_step // world)
+    ms_per_step = elapsed / opts.steps * 1e3
     return {
         'metric': 'tile-iterations/sec, VGG-19 2048px/1024-tile (fwd+bwd, Gram/content losses, '
                   'regularizers, Adam step)',
         'value': tiles_per_step * opts.steps / elapsed,
         'unit': 'tile-iterations/s',
         'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
-        'ms_per_step': elapsed / opts.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tiles of '
-                               '%dx%d per step, %d per GPU' % (max(H, W), TILE, W, H, tiles_per_step,
-                                                             TILE, TILE, TILES_PER_GPU),
+                               '%dx%d per step, %d per busy GPU%s'
+                               % (max(H, W), TILE, W, H, tiles_per_step, TILE, TILE, tiles_per_gpu,
+                                  '' if busy == world else ' (%d of the %d GPUs have no tile: the '
+                                  'workload has only %d)' % (world - busy, world, tiles_per_step)),
                    'content_layers': CONTENT_LAYERS, 'style_layers': STYLE_LAYERS,
-                   'tiles_per_step': tiles_per_step, 'tiles_per_gpu': TILES_PER_GPU,
-                   'final_loss': loss},
-        'roofline': roofline_record(eng, float(np.mean(timed_group_ms))),
+                   'tiles_per_step': tiles_per_step, 'tiles_per_gpu': tiles_per_gpu,
+                   'idle_gpus': world - busy, 'final_loss': loss},
+        'roofline': roofline_record(eng, float(np.mean(timed_group_ms)), tiles_per_gpu, ms_per_step),
     }
 
 
 def bench_single(opts, net, weights, device_index, rows, cols):
     """N = 1: the step loop through TileFarm (four engines = four HIP streams on the GPU)."""
+    from style_transfer_amd import lib
     job = FarmJob(net, weights, [device_index], rows, cols)
     elapsed, loss = job.timed(opts.steps, opts.warmup)
     timed_group_ms = list(job.group_ms)
@@ -467,20 +550,158 @@ def bench_single(opts, net, weights, device_index, rows, cols):
         add_clock(line['roofline'], job.clock)
         line['steady'] = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
                           'value': job.tiles_per_step * n_steady / dt, 'unit': 'tile-iterations/s'}
-    line['graphs'] = job.graph_counters()
+    line['tile_evals'] = int(sum(e.query(lib.Q_TILE_EVALS) for e in job.farm.engines))
     job.close()
     return line
+
+
+class RankJob:
+    """The step loop of one image with one process per GPU (torch.distributed.run): rank 0 owns
+    the image, the optimizer and the regularizers, every rank evaluates tiles t with
+    t mod world == rank on up to STREAMS_PER_GPU engines of its GPU."""
+
+    def __init__(self, net, engines, rank, world, device, rows, cols, wire):
+        import torch
+        from style_transfer_amd import image_ops
+        from style_transfer_amd.dist import DistributedTiles, broadcast_targets
+        from style_transfer_amd.engine import DeviceArray
+        from style_transfer_amd.farm import TileFarm, tile_grid
+        from style_transfer_amd.optimizers import AdamOptimizer
+        self.torch, self.image_ops = torch, image_ops
+        self.net, self.engines, self.rank, self.world, self.device = net, engines, rank, world, device
+        eng = self.eng = engines[0]
+        self.H, self.W = rows * TILE, cols * TILE
+        self.rects = tile_grid((self.H, self.W), TILE)
+        self.tiles_per_rank = -(-len(self.rects) // world)
+        self.wire = wire
+
+        # ---- targets (once, outside the timed region): style Grams and the content map of the
+        # image, computed on rank 0's GPU and broadcast device to device
+        contents, styles = [], []
+        if rank == 0:
+            helper = TileFarm(net, verbose=False, engines=[eng])
+            contents, styles = targets_on(helper, self.H, self.W)
+        contents, styles = broadcast_targets(contents, styles, device)
+        eng.set_contents_and_styles(contents, styles)          # (the rank's other engines share them)
+        eng.sync()
+
+        def wrap(tensor, engine):
+            """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
+            return DeviceArray.from_pointer(engine, tensor.data_ptr(), tensor.shape, owner=tensor)
+
+        self.group_ms = []           # GPU time of one concurrent group of tile evaluations on this rank
+        if rank == 0:
+            self.img = eng.to_device(start_image(self.H, self.W))
+            self.grad = eng.empty((3, self.H, self.W))
+            self.old = eng.empty((3, self.H, self.W)).copy_from(self.img)
+            self.rng = np.random.RandomState(0)
+            self.opt = AdamOptimizer(eng, self.img, step_size=15, bp1=1 - 1 / 20, decay=0.05, power=0.5)
+        inflight = []
+        grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
+                     for _ in range(self.tiles_per_rank)]
+        tile_bufs = {}
+
+        def evaluate_begin(jobs, roll):
+            """Enqueues this rank's tiles, one per engine (they run concurrently)."""
+            inflight.clear()
+            for k, (tile, start) in enumerate(jobs):
+                e = engines[k % len(engines)]
+                inflight.append((e, k, e.sc_grad_tile_async(
+                    wrap(tile, e), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {}, CONTENT_WEIGHT,
+                    STYLE_WEIGHT, grad_out=wrap(grad_bufs[k], e))))
+
+        def evaluate_end():
+            """Waits for them; [(loss, grad tensor)]."""
+            used = []
+            for e, _, _ in inflight:
+                if e not in used:
+                    used.append(e)
+            for e in used:
+                e.sync()
+            self.group_ms.append(max(e.last_tile_ms() for e in used))
+            return [(p.loss, grad_bufs[k]) for _, k, p in inflight]
+
+        def cut(rect, roll):
+            if rect not in tile_bufs:
+                tile_bufs[rect] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
+                                              dtype=torch.float32, device=device)
+            image_ops.cut_tile(eng, self.img, roll, rect, wrap(tile_bufs[rect], eng))
+            return tile_bufs[rect]
+
+        def put(rect, g, roll):
+            image_ops.put_tile(eng, self.grad, roll, rect, wrap(g, eng))
+
+        self.tiles = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0],
+                                      (evaluate_begin, evaluate_end), put, device)
+
+    def step(self):
+        if self.rank != 0:
+            self.tiles.eval_sc_grad(self.rects, (0, 0))
+            return None
+        roll = draw_roll(self.rng, self.H, self.W)
+
+        def opfunc(params):
+            loss = self.tiles.eval_sc_grad(self.rects, roll)
+            reg = self.image_ops.regularizers(self.eng, params, self.grad, MEAN, 5.0, 2.0, 2.0, 6.0)
+            self.eng.sync()
+            return loss + reg.value, self.grad
+        avg, loss = self.opt.update(opfunc)
+        self.image_ops.step_stats(self.eng, avg, self.old)
+        return loss
+
+    def fence(self):
+        import torch.distributed as dist
+        for e in self.engines:
+            e.sync()
+        self.torch.cuda.synchronize()
+        dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed steps, then exactly K steps between two fences (barrier + device
+        synchronisation on both sides); the MAX over ranks."""
+        import torch.distributed as dist
+        loss = None
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.group_ms.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.wire)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]), loss
+
+    def bit_identical(self):
+        """One evaluation over all ranks against the same evaluation on rank 0's GPU alone (a
+        collective call: every rank takes part in the first half).  True / False on rank 0."""
+        from style_transfer_amd.farm import TileFarm
+        roll = draw_roll(np.random.RandomState(123), self.H, self.W)
+        loss_n = self.tiles.eval_sc_grad(self.rects, roll if self.rank == 0 else (0, 0))
+        if self.rank != 0:
+            return None
+        self.eng.sync()
+        grad_n = self.grad.get()
+        solo = TileFarm(self.net, [self.eng.device], verbose=False, engines=list(self.engines))
+        ref = self.eng.empty((3, self.H, self.W))
+        loss_1 = solo.eval_sc_grad(self.img, ref, roll, CONTENT_LAYERS, STYLE_LAYERS, {},
+                                   CONTENT_WEIGHT, STYLE_WEIGHT, TILE)
+        same = bool(loss_n == loss_1 and np.array_equal(grad_n, ref.get()))
+        ref.free()
+        solo.close()
+        return same
 
 
 def bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_one_gpu):
     """N > 1: one process per GPU under torch.distributed.run.  Returns the line on rank 0."""
     import torch
     import torch.distributed as dist
-    from style_transfer_amd import image_ops
-    from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
-    from style_transfer_amd.engine import DeviceArray, TileEngine
-    from style_transfer_amd.farm import TileFarm, tile_grid
-    from style_transfer_amd.optimizers import AdamOptimizer
+    from style_transfer_amd import lib
+    from style_transfer_amd.dist import broadcast_weights
+    from style_transfer_amd.engine import TileEngine
     from style_transfer_amd.weights import synthetic_weights
 
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -488,122 +709,17 @@ def bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_on
     # weights: built once on rank 0 and broadcast with ONE RCCL collective (80 MB); every other
     # rank sets its engines from the received device tensors
     weights = broadcast_weights(synthetic_weights(net, 0) if rank == 0 else None, device)
-    # every rank: TILES_PER_GPU engines (HIP streams) on its GPU sharing one weight bank and one
-    # target set, one tile of the step each
+    # every rank: STREAMS_PER_GPU engines (HIP streams) on its GPU sharing one weight bank and one
+    # target set
     engines = [TileEngine(net, local_rank, weights)]
-    engines += [TileEngine(net, local_rank, share=engines[0]) for _ in range(TILES_PER_GPU - 1)]
-    eng = engines[0]
-    H, W = rows * TILE, cols * TILE
-    rects = tile_grid((H, W), TILE)
-    assert len(rects) % world == 0 and (opts.debug_grid or len(rects) == TILES_PER_GPU * world)
-    tiles_per_rank = len(rects) // world
-    content_weight = {'conv4_2': 0.05}
-    style_weight = {l: 1.0 / len(STYLE_LAYERS) for l in STYLE_LAYERS}
-
-    # ---- targets (once, outside the timed region): style Grams and the content map of the
-    # image, computed on rank 0's GPU and broadcast device to device
-    contents, styles = [], []
-    if rank == 0:
-        helper = TileFarm(net, verbose=False, engines=[eng])
-        style_feats = helper.prepare_features_device(smooth_picture(7, TILE, TILE), STYLE_LAYERS,
-                                                     TILE, passes=1)
-        styles = [{l: eng.gram_matrix(f) for l, f in style_feats.items()}]
-        contents = [helper.prepare_features_device(smooth_picture(8, H, W), CONTENT_LAYERS, TILE,
-                                                   passes=1)]
-    contents, styles = broadcast_targets(contents, styles, device)
-    eng.set_contents_and_styles(contents, styles)          # (the rank's other engines share them)
-    eng.sync()
-
-    def wrap(tensor, engine):
-        """A DeviceArray view of a torch tensor (no copy; torch keeps ownership)."""
-        return DeviceArray.from_pointer(engine, tensor.data_ptr(), tensor.shape, owner=tensor)
-
-    group_ms = []           # GPU time of one concurrent group of tile evaluations on this rank
-    state = {}
-    if rank == 0:
-        rng = np.random.RandomState(0)
-        img = eng.to_device(rng.uniform(0, 255, (3, H, W)).astype(np.float32) -
-                            np.float32(MEAN).reshape(3, 1, 1))
-        state.update(img=img, grad=eng.empty((3, H, W)),
-                     old=eng.empty((3, H, W)).copy_from(img), rng=np.random.RandomState(0),
-                     opt=AdamOptimizer(eng, img, step_size=15, bp1=1 - 1 / 20, decay=0.05,
-                                       power=0.5))
-    inflight = []
-    grad_bufs = [torch.empty((3, TILE, TILE), dtype=torch.float32, device=device)
-                 for _ in range(tiles_per_rank)]
-    tile_bufs = {}
-
-    def evaluate_begin(jobs, roll):
-        """Enqueues this rank's tiles, one per engine (they run concurrently)."""
-        inflight.clear()
-        for k, (tile, start) in enumerate(jobs):
-            e = engines[k % len(engines)]
-            inflight.append((e, k, e.sc_grad_tile_async(
-                wrap(tile, e), start, roll, CONTENT_LAYERS, STYLE_LAYERS, {}, content_weight,
-                style_weight, grad_out=wrap(grad_bufs[k], e))))
-
-    def evaluate_end():
-        """Waits for them; [(loss, grad tensor)]."""
-        used = []
-        for e, _, _ in inflight:
-            if e not in used:
-                used.append(e)
-        for e in used:
-            e.sync()
-        group_ms.append(max(e.last_tile_ms() for e in used))
-        return [(p.loss, grad_bufs[k]) for _, k, p in inflight]
-
-    def cut(rect, roll):
-        if rect not in tile_bufs:
-            tile_bufs[rect] = torch.empty((3, rect[1] - rect[0], rect[3] - rect[2]),
-                                          dtype=torch.float32, device=device)
-        image_ops.cut_tile(eng, state['img'], roll, rect, wrap(tile_bufs[rect], eng))
-        return tile_bufs[rect]
-
-    def put(rect, g, roll):
-        image_ops.put_tile(eng, state['grad'], roll, rect, wrap(g, eng))
-
-    farm = DistributedTiles(lambda rect, roll: (cut(rect, roll), eng.sync())[0],
-                            (evaluate_begin, evaluate_end), put, device)
-
-    def step():
-        if rank != 0:
-            farm.eval_sc_grad(rects, (0, 0))
-            return None
-        xy = np.int32(state['rng'].uniform(-0.5, 0.5, size=2) * (H, W)) // 8
-        roll = xy * 8
-
-        def opfunc(params):
-            loss = farm.eval_sc_grad(rects, roll)
-            reg = image_ops.regularizers(eng, params, state['grad'], MEAN, 5.0, 2.0, 2.0, 6.0)
-            eng.sync()
-            return loss + reg.value, state['grad']
-        avg, loss = state['opt'].update(opfunc)
-        image_ops.step_stats(eng, avg, state['old'])
-        return loss
-
-    def fence():
-        for e in engines:
-            e.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
+    engines += [TileEngine(net, local_rank, share=engines[0]) for _ in range(STREAMS_PER_GPU - 1)]
     wire = 'cpu' if debug_one_gpu else device
-    loss = None
-    for _ in range(opts.warmup):
-        step()
-    fence()
-    group_ms.clear()
-    t0 = time.perf_counter()
-    for _ in range(opts.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=wire)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
-    timed_group_ms = list(group_ms)
+
+    # ---- the headline: BASELINE's literal workload (strong scaling)
+    job = RankJob(net, engines, rank, world, device, rows, cols, wire)
+    same = job.bit_identical()
+    elapsed, loss = job.timed(opts.steps, opts.warmup)
+    timed_group_ms = list(job.group_ms)
 
     # ---- a second, longer measurement of the same loop (the timed region above is short)
     steady = None
@@ -613,25 +729,41 @@ def bench_ranks(opts, net, rank, world, local_rank, device, rows, cols, debug_on
                          dtype=torch.int64, device=wire)
         dist.broadcast(t, 0)
         n_steady = int(t[0])
-        fence()
         if rank == 0:
             for e in engines:
                 e.clock_marks(True)
-        t1 = time.perf_counter()
-        for _ in range(n_steady):
-            step()
-        fence()
-        dt = time.perf_counter() - t1
+        dt, _ = job.timed(n_steady, 0)
         if rank == 0:
             clock = clock_summary(engines)
         steady = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
-                  'value': len(rects) * n_steady / dt, 'unit': 'tile-iterations/s'}
+                  'value': len(job.rects) * n_steady / dt, 'unit': 'tile-iterations/s'}
     line = None
     if rank == 0:
-        line = base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms)
+        line = base_line(opts, world, rows, cols, elapsed, loss, engines[0], timed_group_ms)
+        line['layout'] = 'one process per GPU (torch.distributed.run), tiles and gradients as batched ' \
+                         'point-to-point transfers over %s, no collective on the data path' \
+                         % ('gloo through host memory (STX_BENCH_DEBUG_ONE_GPU: every rank on GPU 0)'
+                            if debug_one_gpu else 'RCCL / xGMI')
+        line['bit_identical'] = same
+        line['peers_without_access'] = int(engines[0].query(lib.Q_PEERS_WITHOUT_ACCESS))
         add_clock(line['roofline'], clock)
         if steady is not None:
             line['steady'] = steady
+
+    # ---- the weak-scaling sub-record (rounds 1-3's headline): four tiles per GPU, growing image
+    if not opts.no_weak and not opts.debug_grid:
+        wr, wc = WEAK_GRIDS[world]
+        weak = RankJob(net, engines, rank, world, device, wr, wc, wire)
+        weak_same = weak.bit_identical()
+        w_elapsed, w_loss = weak.timed(opts.steps, min(opts.warmup, 2))
+        if rank == 0:
+            line['weak'] = {'scaling': 'weak', 'n_gpus': world,
+                            'workload': 'VGG-19 %dx%d image, %d tiles of %dx%d per step, %d per GPU, -o adam'
+                                        % (weak.W, weak.H, len(weak.rects), TILE, TILE, STREAMS_PER_GPU),
+                            'value': len(weak.rects) * opts.steps / w_elapsed, 'unit': 'tile-iterations/s',
+                            'ms_per_step': w_elapsed / opts.steps * 1e3, 'steps': opts.steps,
+                            'final_loss': w_loss, 'avg_launch_ms': float(np.mean(weak.group_ms)),
+                            'bit_identical': weak_same}
     # every rank lets go of its GPU before rank 0 goes on alone (farm and whole-run legs drive
     # all GPUs from one process); no collective is pending past this point
     dist.barrier()

@@ -101,9 +101,10 @@ typedef enum stx_query {
     STX_Q_TARGET_UPLOADS = 1,  /* stx_set_contents_and_styles calls served by this group */
     STX_Q_TARGET_BYTES = 2,    /* bytes those calls copied, cumulative */
     STX_Q_WEIGHT_BYTES = 3,    /* device bytes of weights + packed banks held by this group */
-    STX_Q_GRAPH_CAPTURES = 4,  /* tile evaluations recorded as launch graphs by this engine */
-    STX_Q_GRAPH_REPLAYS = 5,   /* tile evaluations served by replaying a recording */
-    STX_Q_EAGER_TILES = 6      /* tile evaluations enqueued kernel by kernel */
+    STX_Q_TILE_EVALS = 4,      /* stx_sc_grad_tile calls enqueued by this engine */
+    STX_Q_PEERS_WITHOUT_ACCESS = 5  /* GPUs of the node this engine's GPU has no direct (xGMI peer)
+                                     * access to: copies to / from them are staged by the runtime
+                                     * (reported once on stderr) */
 } stx_query;
 int stx_engine_query(stx_engine *e, int what, double *value);
 int stx_engine_device(stx_engine *e, int *device);

@@ -23,7 +23,6 @@ SOURCES = {
     'conv_wino.hip': [],
     'conv_wino2.hip': [],
     'conv_wino4.hip': [],
-    'conv_bf3.hip': [],
     'gram.hip': [],
     'symm.hip': [],
     'pool.hip': [],

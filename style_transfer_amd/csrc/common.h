@@ -82,10 +82,6 @@ struct ContentWindow {
     int ch, cw;             // full content map size
     int oy, ox;             // window origin in the rolled map
     int sy, sx;             // roll shifts (rows, cols)
-    // Replayed launch graphs (engine.cpp: TileGraph) cannot carry the iteration's shift as a
-    // kernel argument: when non-null, {oy - sy, ox - sx} is read from these two device ints
-    // (written on the stream just before the graph is launched) and oy/ox/sy/sx are ignored.
-    const int *dyn = nullptr;
 };
 
 // Loss-gradient terms added by the backward-data epilogue to the gradient it produces (the
@@ -130,7 +126,9 @@ struct ConvProblem {
                                      // wino2_fuses_pool)
     float *splitk_ws = nullptr;      // scratch for split-K partial sums (optional)
     size_t splitk_ws_floats = 0;
-    const void *x_split = nullptr;   // conv_bf3.hip: the input as bf3_split_launch wrote it (optional)
+#ifdef STX_EXPERIMENT_BF3
+    const void *x_split = nullptr;   // tools/experiments/conv_bf3.hip only
+#endif
 };
 
 // Tile configuration chosen for a problem; weights must be packed for the same (bm, kc).
@@ -180,7 +178,9 @@ struct WinoArgs {
     int skip_y = 0;                             // forward + fused pooling with codes: y is not stored
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
-    int vp_rows = 0, vp_tp = 0;                 // conv_bf3.hip, pre-split operand: rows / x-tiles per row of a plane
+#ifdef STX_EXPERIMENT_BF3
+    int vp_rows = 0, vp_tp = 0;                 // tools/experiments/conv_bf3.hip only
+#endif
 };
 
 // 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
@@ -192,16 +192,6 @@ int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int t
                       const ConvConfig &cfg, float *packed);
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
-// 1-D Winograd on the bf16 matrix cores with three-piece operands (conv_bf3.hip); config id 300.
-ConvConfig bf3_config();
-size_t bf3_packed_floats(int K, int M);
-int bf3_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed);
-int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
-bool bf3_usable(const ConvProblem &p);      // what the kernel takes (shape, epilogue, addressing)
-// The pre-split form: bf3_split_launch writes the transformed, three-piece operand of a whole layer
-// once (bf3_split_bytes of scratch), bf3_launch with p.x_split set reads it instead of p.x.
-size_t bf3_split_bytes(int K, int H, int W);
-int bf3_split_launch(hipStream_t s, const float *x, int K, int H, int W, void *split);
 
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
 ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16, 2: 8 x 32
@@ -266,10 +256,9 @@ int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigne
 // sums[0] = sum (F - Fc)^2, sums[1] = sum |F - Fc| over the tile window of the (virtually rolled)
 // content map.
 #ifdef __HIPCC__
-// Window origin in the un-rolled content map, before wrapping: (oy - sy, ox - sx), or the two
-// device ints of a replayed launch graph (ContentWindow::dyn; uniform scalar loads).
-__device__ __forceinline__ int content_origin_y(const ContentWindow &w) { return w.dyn ? w.dyn[0] : w.oy - w.sy; }
-__device__ __forceinline__ int content_origin_x(const ContentWindow &w) { return w.dyn ? w.dyn[1] : w.ox - w.sx; }
+// Window origin in the un-rolled content map, before wrapping: (oy - sy, ox - sx).
+__device__ __forceinline__ int content_origin_y(const ContentWindow &w) { return w.oy - w.sy; }
+__device__ __forceinline__ int content_origin_x(const ContentWindow &w) { return w.ox - w.sx; }
 // Rolled content value at tile-feature position (c, y, x):
 // roll2(Fc, (sx, sy))[c][oy + y][ox + x] = Fc[c][(oy + y - sy) mod ch][(ox + x - sx) mod cw]
 __device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, int y, int x) {
@@ -289,7 +278,6 @@ int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef, bool accumulate);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
-int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n);
 int clock_mark_launch(hipStream_t s, long long *out, long long ticks);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
 int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,

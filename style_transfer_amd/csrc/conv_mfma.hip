@@ -513,7 +513,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
 
 int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     if (!packed || p.ksize != 3 || (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad)) return 1;
-    if (cfg.id >= 300) return 1;
     if (cfg.id >= 200) return wino2_splitk_factor(cfg, p);
     if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;   // (ids 100-102: 1-D Winograd, allowed)
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);

@@ -604,10 +604,9 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
 
     {
         const float *const content = a.inj.content;
-        const int *const cw_dyn = a.inj.win.dyn;     // replayed launch graph: origin in device memory
         const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw,
-                  cw_oy = cw_dyn ? cw_dyn[0] : a.inj.win.oy - a.inj.win.sy,
-                  cw_ox = cw_dyn ? cw_dyn[1] : a.inj.win.ox - a.inj.win.sx;
+                  cw_oy = a.inj.win.oy - a.inj.win.sy,
+                  cw_ox = a.inj.win.ox - a.inj.win.sx;
         // common.h: content_index -- the wrapped row / column of the lane's 2 x 2 outputs in the
         // full-image content map, once per lane (two integer divisions per OUTPUT were ~1300
         // vector instructions of this epilogue on the content layer)

@@ -359,10 +359,9 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(WinoArgs a) {
     }
     // (scalars, not a reference to a.inj.win: taking the address of a member of the argument
     // block sends the whole block to scratch)
-    const int *const cw_dyn = a.inj.win.dyn;     // replayed launch graph: origin in device memory
     const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw,
-              cw_oy = cw_dyn ? cw_dyn[0] : a.inj.win.oy - a.inj.win.sy,
-              cw_ox = cw_dyn ? cw_dyn[1] : a.inj.win.ox - a.inj.win.sx;
+              cw_oy = a.inj.win.oy - a.inj.win.sy,
+              cw_ox = a.inj.win.ox - a.inj.win.sx;
     const float *const content = a.inj.content;
     auto content_at = [&](int c, int y, int x) __attribute__((always_inline)) {      // common.h: content_index
         int ry_ = (cw_oy + y) % cw_ch, rx_ = (cw_ox + x) % cw_cw;

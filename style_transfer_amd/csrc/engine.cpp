@@ -34,10 +34,6 @@ void set_error(const char *fmt, ...) {
     g_error = buf;
 }
 
-// Bumped whenever a DevBuf is (re)allocated or released: a recorded launch graph (TileGraph) holds
-// raw device pointers and is only replayed while the epoch it was captured under still stands.
-static std::atomic<unsigned long> g_alloc_epoch{0};
-
 // Growable device buffer.  Growth frees and reallocates (hipFree synchronises the device, so
 // kernels still reading the old allocation have finished); it happens only when a larger tile
 // than ever before arrives.
@@ -46,7 +42,6 @@ struct DevBuf {
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return STX_OK;
-        ++g_alloc_epoch;
         if (ptr) STX_HIP(hipFree(ptr));
         ptr = nullptr;
         bytes = 0;
@@ -61,10 +56,7 @@ struct DevBuf {
         return STX_OK;
     }
     void release() {
-        if (ptr) {
-            ++g_alloc_epoch;
-            (void)hipFree(ptr);
-        }
+        if (ptr) (void)hipFree(ptr);
         ptr = nullptr;
         bytes = 0;
     }
@@ -118,7 +110,6 @@ struct PendingLoss {
     double *out;
     std::vector<LossTerm> terms;       // sum coef * scalar
     std::vector<LossTerm> dterms;      // sum coef * double scalar (image ops)
-    const float *host = nullptr;       // mirror the float terms index (null: the engine's own)
 };
 
 // What the engines of one GPU have in common: the network's weights, the banks packed for the
@@ -136,47 +127,6 @@ struct SharedState {
     double target_bytes = 0;           // bytes those calls copied (cumulative)
 };
 
-// One content-map window of a recorded tile evaluation: what is needed to recompute its origin
-// for the call at hand (start // scale - roll // scale) and to re-validate it.
-struct DynWindow {
-    int scale, fh, fw, ch, cw;
-    std::string blob;
-};
-
-// A recorded stx_sc_grad_tile: everything between the tile landing in the input blob and the
-// gradient standing in its diff, as one hipGraph.  The launch-bound small scales of a pyramid
-// spend ~17 us of host time per kernel on ~65 kernels per tile (1.19 ms for a 256^2 tile whose
-// kernels need less than half of that); a replay is one call.  Per-call state that the recorded
-// kernels cannot carry as arguments lives in device memory owned by the graph: the content
-// windows' origins (`dyn`, rewritten before every launch) and the loss scalars.
-struct TileGraph {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    unsigned long epoch = 0;
-    int eager_calls = 0;               // evaluations of this key run eagerly so far (same epoch)
-    bool disabled = false;             // capture failed once: stay eager
-    bool in_flight = false;            // launched since the last stx_sync (its scalars are unread)
-    float *scalars = nullptr;          // loss scalars of this recording (raw allocations: they must not
-    int *dyn = nullptr;                // move the allocation epoch) and the content-window origins
-    float *scalars_host = nullptr;
-    size_t scalars_cap = 0, scalars_used = 0;
-    std::vector<DynWindow> windows;
-    std::vector<LossTerm> terms;
-    double flop_algorithmic = 0, flop_issued = 0;
-    void destroy_graph() {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        exec = nullptr;
-        graph = nullptr;
-    }
-    ~TileGraph() {
-        destroy_graph();
-        if (scalars) (void)hipFree(scalars);
-        if (dyn) (void)hipFree(dyn);
-        if (scalars_host) (void)hipHostFree(scalars_host);
-    }
-};
-
 }  // namespace stx
 
 using namespace stx;
@@ -184,15 +134,10 @@ using namespace stx;
 struct stx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;            // where the loss terms of the current call run: stream or side2
-    hipStream_t side2 = nullptr;           // second stream for them (small tiles, see stx_sc_grad_tile)
     bool clock_marks = false;              // stx_clock_marks: two marks per tile evaluation
     DevBuf marks_buf;
     int marks_used = 0;
-    int side_mode = 0;                     // STX_SIDE_STREAM: 0 / unset never, 1 always, "auto" (-1): small tiles
-    hipEvent_t ev_fwd = nullptr;
-    std::vector<hipEvent_t> ev_tap;
-    std::vector<std::unique_ptr<DevBuf>> sgrad_tap;
+    std::vector<std::unique_ptr<DevBuf>> sgrad_tap;   // S = sym(D) F of every style tap
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
     double flop_algorithmic = 0, flop_issued = 0;   // matrix work of the current / last tile call
@@ -206,20 +151,7 @@ struct stx_engine {
     DevBuf scalars;                    // device floats
     float *scalars_host = nullptr;     // pinned mirror
     size_t scalars_cap = 0, scalars_used = 0;
-    // the arena alloc_scalars serves from: the engine's own, or a TileGraph's while it is recorded
-    float *arena_dev = nullptr;
-    size_t arena_cap = 0, *arena_used = nullptr;
-    // recorded tile evaluations (STX_GRAPH=0 turns them off), keyed by everything a recording bakes in
-    // A recording costs ~12 ms (capture + instantiate) and saves ~45 us of a 4-stream step per
-    // replay, nothing at the single-tile scales: it pays for itself after
-    // ~270 replays, so a key is recorded only once it has been evaluated that often kernel by
-    // kernel -- a pyramid level of 100-200 iterations never is (13 recordings made a whole
-    // `--size 2048` run 0.15 s SLOWER).  STX_GRAPH_MIN_EAGER=2 records at the third evaluation.
-    bool graphs_on = true;
-    int graph_min_eager = 300;
-    TileGraph *recording = nullptr;
-    std::map<std::string, std::unique_ptr<TileGraph>> graphs;
-    size_t n_captures = 0, n_replays = 0, n_eager = 0;
+    size_t n_tile_evals = 0;               // stx_sc_grad_tile calls (STX_Q_TILE_EVALS)
     std::vector<hipEvent_t> fence_events;     // stx_engine_wait: ring of events recorded on this stream
     size_t fence_next = 0;
     DevBuf dscalars;                   // device doubles (image-op reductions)
@@ -292,19 +224,13 @@ double conv_flops(int K, int M, int H, int W, int ks) {
 
 
 int alloc_scalars(stx_engine *e, size_t n, size_t *index) {
-    if (*e->arena_used + n > e->arena_cap) {
-        set_error("scalar arena exhausted (%zu + %zu > %zu)", *e->arena_used, n, e->arena_cap);
+    if (e->scalars_used + n > e->scalars_cap) {
+        set_error("scalar arena exhausted (%zu + %zu > %zu)", e->scalars_used, n, e->scalars_cap);
         return STX_ERR_NOMEM;
     }
-    *index = *e->arena_used;
-    *e->arena_used += n;
+    *index = e->scalars_used;
+    e->scalars_used += n;
     return STX_OK;
-}
-
-void use_own_arena(stx_engine *e) {
-    e->arena_dev = e->scalars.f();
-    e->arena_cap = e->scalars_cap;
-    e->arena_used = &e->scalars_used;
 }
 
 int alloc_dscalars(stx_engine *e, size_t n, size_t *index) {
@@ -379,13 +305,9 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
     }
-    const int key = dir * 1024 + (cfg.id >= 300 ? 300 : cfg.id >= 200 ? 200 : cfg.id);   // the 2-D geometries share a bank
+    const int key = dir * 1024 + (cfg.id >= 200 ? 200 : cfg.id);   // the 2-D geometries share a bank
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
-        if (e->recording) {
-            set_error("a filter bank would have to be packed while a launch graph is recorded");
-            return STX_ERR_STATE;
-        }
         const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
         std::unique_ptr<DevBuf> buf(new DevBuf);
         if (cfg.id >= 100) {   // Winograd-transformed bank
@@ -524,9 +446,7 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
     // chosen kernel puts on the matrix cores (tile padding not counted)
     const double direct = 2.0 * p.M * p.K * p.ksize * p.ksize * (double)p.H * p.W;
     e->flop_algorithmic += direct;
-    // (id 300: 6 of 9 multiplies, each as six bf16 products of 1/16 of an fp32 MFMA's time per k)
-    e->flop_issued += cfg.id >= 300   ? direct * (6.0 / 9.0) * 0.375
-                      : cfg.id >= 200 ? direct * 4.0 / 9.0
+    e->flop_issued += cfg.id >= 200   ? direct * 4.0 / 9.0
                       : cfg.id >= 100 ? direct * 2.0 / 3.0
                                       : direct;
     if (cfg.id >= 100) return wino_launch(e->stream, cfg, p, conv_splitk_factor(cfg, p, true));
@@ -537,20 +457,9 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
 // eight-wave 2-D Winograd kernel does, the four-wave one (ids 210+) writes the pooled values only.
 static bool conv_writes_pool_codes(const ConvConfig &cfg) { return cfg.id >= 200 && cfg.id < 210; }
 
-// STX_CONV_BF3=1: plain 3x3 layers with at least 128 input channels and a plane that fills the chip
-// run on the bf16 matrix cores with three-piece operands (conv_bf3.hip) -- not the layers whose
-// pooling is fused into the convolution, not the loss-injecting ones.  Read at every call.
-static bool bf3_wanted(const ConvProblem &p, bool fused_pool, bool inject) {
-    const char *env = getenv("STX_CONV_BF3");
-    if (!env || atoi(env) == 0 || fused_pool || inject || p.mask_codes) return false;
-    if (p.K < (atoi(env) > 1 ? atoi(env) : 128) || !bf3_usable(p)) return false;
-    const ConvConfig c = bf3_config();
-    return (long)ceil_div(p.M, c.bm) * ceil_div(p.H, c.pr) * ceil_div(p.W, c.pc) >= 256;
-}
-
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
-    return cfg.id >= 200 && cfg.id < 300 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
+    return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
 }
 
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
@@ -574,7 +483,6 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     p.epilogue = kEpiForward;
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
-    if (bf3_wanted(p, pool != nullptr, false)) cfg = bf3_config();
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
@@ -655,7 +563,6 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
-    if (bf3_wanted(p, false, inj != nullptr)) cfg = bf3_config();
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
@@ -797,15 +704,13 @@ int end_timing(stx_engine *e) {
 int publish_pending(stx_engine *e) {
     for (const PendingLoss &pl : e->pending) {
         double v = 0.0;
-        const float *host = pl.host ? pl.host : e->scalars_host;
-        for (const LossTerm &t : pl.terms) v += t.coef * (double)host[t.scalar_index];
+        for (const LossTerm &t : pl.terms) v += t.coef * (double)e->scalars_host[t.scalar_index];
         for (const LossTerm &t : pl.dterms) v += t.coef * e->dscalars_host[t.scalar_index];
         if (pl.out) *pl.out = v;
     }
     e->pending.clear();
     e->scalars_used = 0;
     e->dscalars_used = 0;
-    for (auto &kv : e->graphs) kv.second->in_flight = false;
     return STX_OK;
 }
 
@@ -853,6 +758,47 @@ int stx_device_name(int device, char *buf, size_t buf_len) {
 }
 
 }  // extern "C"
+
+// Peer access between the GPUs of the node (tile and target copies of a multi-GPU farm are peer
+// reads / writes over xGMI).  Tried once per device; a pair that cannot be enabled is remembered
+// and reported once on stderr -- copies between those two GPUs still work (the runtime stages
+// them through host memory), they are only slower.  STX_Q_PEERS_WITHOUT_ACCESS counts them.
+static std::mutex g_peer_mutex;
+static std::map<int, std::vector<int>> g_peers_missing;   // device -> peers without direct access
+
+void enable_peer_access(int device) {
+    std::lock_guard<std::mutex> lock(g_peer_mutex);
+    if (g_peers_missing.count(device)) return;
+    std::vector<int> &missing = g_peers_missing[device];
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (int peer = 0; peer < n_dev; ++peer) {
+        if (peer == device) continue;
+        int can = 0;
+        hipError_t err = hipDeviceCanAccessPeer(&can, device, peer);
+        if (err == hipSuccess && can) {
+            err = hipDeviceEnablePeerAccess(peer, 0);
+            if (err == hipErrorPeerAccessAlreadyEnabled) err = hipSuccess;
+        } else if (err == hipSuccess) {
+            err = hipErrorPeerAccessUnsupported;
+        }
+        (void)hipGetLastError();
+        if (err != hipSuccess) {
+            missing.push_back(peer);
+            fprintf(stderr, "libstx: no peer access GPU %d -> GPU %d (%s); copies between them are "
+                            "staged by the runtime\n", device, peer, hipGetErrorString(err));
+        }
+    }
+}
+
+int peers_without_access(int device) {
+    std::lock_guard<std::mutex> lock(g_peer_mutex);
+    auto it = g_peers_missing.find(device);
+    return it == g_peers_missing.end() ? 0 : (int)it->second.size();
+}
 
 // `share`: the state of an engine on the same GPU to join (weights, packed banks, targets), or null.
 static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
@@ -962,33 +908,8 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
         }
         for (size_t bi = 0; bi < e->blobs.size(); ++bi) e->blobs[bi].scale = 224 / h224[bi];
     }
-    // let this GPU read and write the other GPUs of the node directly (tile and target copies of a
-    // multi-GPU farm go over xGMI); harmless when there is one GPU or access is already enabled
-    {
-        int n_dev = 0;
-        if (hipGetDeviceCount(&n_dev) == hipSuccess) {
-            for (int peer = 0; peer < n_dev; ++peer) {
-                int can = 0;
-                if (peer == device || hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can)
-                    continue;
-                (void)hipDeviceEnablePeerAccess(peer, 0);
-            }
-            (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is expected
-        }
-    }
+    enable_peer_access(device);
     STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    // The loss terms can run on a second stream beside the backward convolutions
-    // (STX_SIDE_STREAM=1).  Measured on MI355X this is 1.7 % SLOWER (13.24 vs 13.02 ms per 1024^2
-    // tile): the conv kernels already keep every CU's matrix pipe ~90 % busy, so co-resident
-    // Gram / SYMM workgroups only displace conv workgroups.  Default: in order on one stream.
-    // STX_SIDE_STREAM=auto does it for tiles of up to 512 x 512 only, where the chip is not full:
-    // stepping one scale in isolation gains (256 px 8 %, 362 px 6 %, 512 px 3 %,
-    // tools/scale_steps.py), the whole `--size 2048` run does not (5.94 vs 5.90 s of stepping, three
-    // alternating pairs on one box), so it stays a switch.  The choice is made per call.
-    if (const char *env = getenv("STX_SIDE_STREAM")) e->side_mode = !strcmp(env, "auto") ? -1 : atoi(env) != 0;
-    STX_HIP(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
-    e->side = e->stream;
-    STX_HIP(hipEventCreateWithFlags(&e->ev_fwd, hipEventDisableTiming));
     STX_HIP(hipEventCreate(&e->ev_start));
     STX_HIP(hipEventCreate(&e->ev_stop));
     STX_HIP(hipEventCreate(&e->ev_tune0));
@@ -996,8 +917,6 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
     if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
     if (const char *env = getenv("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
     if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
-    if (const char *env = getenv("STX_GRAPH")) e->graphs_on = atoi(env) != 0;
-    if (const char *env = getenv("STX_GRAPH_MIN_EAGER")) e->graph_min_eager = std::max(1, atoi(env));
     e->scalars_cap = kScalarFloats;
     STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
@@ -1006,7 +925,6 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
     STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->dscalars_host),
                           e->dscalars_cap * sizeof(double), hipHostMallocDefault));
     STX_TRY(e->red_scratch.ensure(4 * 1024 * sizeof(float)));
-    use_own_arena(e.get());
     {
         std::lock_guard<std::mutex> lock(e->sh->mutex);
         e->sh->members.push_back(e.get());
@@ -1040,6 +958,10 @@ int stx_engine_create_shared(stx_engine *primary, stx_engine **out) {
         d.stride = L.stride;
         d.pool_mode = L.pool_mode;
     }
+    // every filter bank the group has packed so far (and its weights and targets) is complete
+    // before the new member's stream can touch it
+    STX_TRY(primary->set_device());
+    for (stx_engine *m : primary->sh->members) STX_HIP(hipStreamSynchronize(m->stream));
     return build_engine(primary->device, descs.data(), (int)descs.size(), primary->sh, out);
 }
 
@@ -1047,11 +969,7 @@ void stx_engine_destroy(stx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->side2) (void)hipStreamSynchronize(e->side2);
     for (auto &b : e->sgrad_tap) b->release();
-    for (hipEvent_t ev : e->ev_tap) (void)hipEventDestroy(ev);
-    if (e->ev_fwd) (void)hipEventDestroy(e->ev_fwd);
-    if (e->side2) (void)hipStreamDestroy(e->side2);
     e->marks_buf.release();
     for (Blob &b : e->blobs) {
         b.data.release();
@@ -1059,7 +977,6 @@ void stx_engine_destroy(stx_engine *e) {
         b.codes.release();
         b.relu_codes.release();
     }
-    e->graphs.clear();
     for (hipEvent_t ev : e->fence_events) (void)hipEventDestroy(ev);
     bool last;
     {
@@ -1178,9 +1095,8 @@ int stx_engine_query(stx_engine *e, int what, double *value) {
             *value = b;
             break;
         }
-        case STX_Q_GRAPH_CAPTURES: *value = (double)e->n_captures; break;
-        case STX_Q_GRAPH_REPLAYS: *value = (double)e->n_replays; break;
-        case STX_Q_EAGER_TILES: *value = (double)e->n_eager; break;
+        case STX_Q_TILE_EVALS: *value = (double)e->n_tile_evals; break;
+        case STX_Q_PEERS_WITHOUT_ACCESS: *value = (double)peers_without_access(e->device); break;
         default:
             set_error("stx_engine_query: unknown item %d", what);
             return STX_ERR_ARG;
@@ -1328,8 +1244,6 @@ int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int 
 
 namespace {
 
-constexpr size_t kMaxDynWindows = 32;
-
 struct Tap {
     int blob;
     const stx_tap *t;
@@ -1405,28 +1319,25 @@ int sc_grad_prepare(stx_engine *e, const TileCall &c, TilePlan &plan) {
     return shape_blobs(e, c.th, c.tw, needed, true);
 }
 
-// Enqueues the evaluation proper: forward pass with the loss terms of the tapped blobs, backward
-// walk, the mirror copy of the loss scalars.  The tile is already in the input blob; the gradient
-// is left in its diff.  `g` non-null: the stream is being recorded into g (no timing events; the
-// content windows take their origin from g's device memory).
 constexpr int kMaxClockMarks = 8192;
 
 // stx_clock_marks: after the forward pass and at the end of the backward pass
 int clock_mark(stx_engine *e) {
-    if (!e->clock_marks || e->recording || e->marks_used >= kMaxClockMarks) return STX_OK;
+    if (!e->clock_marks || e->marks_used >= kMaxClockMarks) return STX_OK;
     long long *out = static_cast<long long *>(e->marks_buf.ptr) + 2 * (size_t)e->marks_used++;
     return clock_mark_launch(e->stream, out, 2000);
 }
 
-int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingLoss &pl, TileGraph *g) {
+// Enqueues the evaluation proper: forward pass with the loss terms of the tapped blobs, backward
+// walk, the mirror copy of the loss scalars.  The tile is already in the input blob; the gradient
+// is left in its diff.
+int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingLoss &pl) {
     const std::vector<Tap> &order = plan.order;
     const std::vector<char> &needed = plan.needed;
     const std::vector<int> &tap_of = plan.tap_of;
     const int data_blob = e->layers[0].top_blob;
 
-    // ---- loss terms of the tapped blobs.  They depend only on the forward activations, so they
-    // are all queued right after the forward pass (optionally on a side stream, see
-    // stx_engine_create); the backward walk waits for a tap's event where it reaches that blob.
+    // ---- loss terms of the tapped blobs
     struct Term {
         bool style;
         const float *src;        // style: S = sym(tril(G - Gs)) F;  content: the content map
@@ -1435,18 +1346,11 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         ContentWindow win;
     };
     std::vector<std::vector<Term>> terms(order.size());
-    const bool two_streams = e->side != e->stream;
-    while (e->ev_tap.size() < order.size()) {
-        hipEvent_t ev;
-        STX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        e->ev_tap.push_back(ev);
-    }
     while (e->sgrad_tap.size() < order.size()) e->sgrad_tap.emplace_back(new DevBuf);
-    // Loss terms of tap k (Gram -> G - Gs -> SYMM, content residual sums).  With one stream they
-    // are queued the moment the tapped blob is complete, in the middle of the forward pass, while
-    // the blob is still in the L2 / Infinity Cache the convolution just wrote it through (the
-    // shallow blobs were re-fetched from HBM when all taps ran after the forward pass: 1.1 GB
-    // per tile by PMC); with a side stream (STX_SIDE_STREAM=1) they run after it, as before.
+    // Loss terms of tap k (Gram -> G - Gs -> SYMM, content residual sums).  They are queued the
+    // moment the tapped blob is complete, in the middle of the forward pass, while the blob is
+    // still in the L2 / Infinity Cache the convolution just wrote it through (the shallow blobs
+    // were re-fetched from HBM when all taps ran after the forward pass: 1.1 GB per tile by PMC).
     auto launch_terms = [&](size_t k) -> int {
         const Tap &tp = order[k];
         Blob &b = e->blobs[tp.blob];
@@ -1472,20 +1376,12 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                               win.oy, win.fh, win.ox, win.fw, win.ch, win.cw, b.name.c_str());
                     return STX_ERR_ARG;
                 }
-                if (g) {    // recorded: the origin is read from device memory at run time
-                    win.dyn = g->dyn + 2 * g->windows.size();
-                    g->windows.push_back(DynWindow{b.scale, b.h, b.w, ct.h, ct.w, b.name});
-                    if (g->windows.size() > kMaxDynWindows) {
-                        set_error("too many content windows for one launch graph");
-                        return STX_ERR_UNSUPPORTED;
-                    }
-                }
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-                float *sums = e->arena_dev + si;
+                float *sums = e->scalars.f() + si;
                 {
-                    ProfScope scope(e, "content " + b.name, 0.0, e->side);
-                    STX_TRY(content_sums_launch(e->side, b.data.f(), ct.feat->f(), win, sums));
+                    ProfScope scope(e, "content " + b.name, 0.0, e->stream);
+                    STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
                 }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->content_weight * 0.5});
                 terms[k].push_back(Term{false, ct.feat->f(), sums,
@@ -1516,8 +1412,8 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 float *sgrad = e->sgrad_tap[k]->f() + (size_t)slot++ * b.count();
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
-                float *sc = e->arena_dev + si;   // [0] = sum tril(D)^2, [1] = sum |S|
-                STX_TRY(launch_style_terms(e, e->side, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
+                float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
+                STX_TRY(launch_style_terms(e, e->stream, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
                                            b.name));
                 (void)HW;
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
@@ -1534,32 +1430,28 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             win.fw = win.cw = b.w;
             size_t si;
             STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-            float *sums = e->arena_dev + si;
+            float *sums = e->scalars.f() + si;
             {
-                ProfScope scope(e, "dream " + b.name, 0.0, e->side);
-                STX_TRY(content_sums_launch(e->side, b.data.f(), nullptr, win, sums));
+                ProfScope scope(e, "dream " + b.name, 0.0, e->stream);
+                STX_TRY(content_sums_launch(e->stream, b.data.f(), nullptr, win, sums));
             }
             pl.terms.push_back(LossTerm{si, -lw * tp.t->dd_weight * 0.5});
             terms[k].push_back(Term{false, nullptr, sums, (float)(-lw * tp.t->dd_weight), win});
         }
-        if (two_streams) STX_HIP(hipEventRecord(e->ev_tap[k], e->side));
         return STX_OK;
     };
     // (STX_TERMS_LATE=1: all loss terms after the forward pass, for A/B measurements)
-    const bool interleave = e->side == e->stream && !(getenv("STX_TERMS_LATE") && atoi(getenv("STX_TERMS_LATE")));
+    const bool interleave = !(getenv("STX_TERMS_LATE") && atoi(getenv("STX_TERMS_LATE")));
     const std::function<int(int)> hook = [&](int blob) -> int {
         const int k = tap_of[blob];
         return k >= 0 ? launch_terms((size_t)k) : STX_OK;
     };
-    if (!g) STX_TRY(begin_timing(e));
-    e->flop_algorithmic = e->flop_issued = 0;
+    STX_TRY(begin_timing(e));
     std::vector<char> observed(e->blobs.size(), 0);
     for (const Tap &tp : order) observed[tp.blob] = 1;
     STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true, &observed));
     STX_TRY(clock_mark(e));
     if (!interleave) {
-        STX_HIP(hipEventRecord(e->ev_fwd, e->stream));
-        STX_HIP(hipStreamWaitEvent(e->side, e->ev_fwd, 0));
         // (shallowest tap first, the order the interleaved schedule queues them in: the host adds
         // the loss terms up in queueing order, in double precision, and must get the same bits)
         for (size_t k = order.size(); k-- > 0;) STX_TRY(launch_terms(k));
@@ -1594,7 +1486,6 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
     int cur = order[0].blob;
     {
-        if (two_streams) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[0], 0));
         bool written = false;
         STX_TRY(inject(0, written));
         if (!written)
@@ -1607,7 +1498,6 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         Blob &bot = e->blobs[L.bottom_blob];
         const Blob &top = e->blobs[cur];
         const int k = tap_of[L.bottom_blob];
-        if (k >= 0 && two_streams) STX_HIP(hipStreamWaitEvent(e->stream, e->ev_tap[k], 0));
         bool fused = false;
         if (L.type == STX_LAYER_CONV) {
             ConvInject inj{};
@@ -1645,133 +1535,10 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         }
     }
     STX_TRY(clock_mark(e));
-    if (!g) STX_TRY(end_timing(e));
+    STX_TRY(end_timing(e));
     // mirror the scalars used so far (small) for the loss
-    STX_HIP(hipMemcpyAsync(g ? g->scalars_host : e->scalars_host, e->arena_dev,
-                           *e->arena_used * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    return STX_OK;
-}
-
-// Everything a recording bakes in: tile shape, taps (blobs, flags, weights) and, through the
-// allocation epoch checked by the caller, every device pointer.  `instance` tells apart several
-// uses of one key between two stx_sync calls (each owns its loss scalars).
-std::string graph_key(stx_engine *e, const TileCall &c, int instance) {
-    std::string key;
-    auto put = [&](const void *p, size_t n) { key.append(static_cast<const char *>(p), n); };
-    const int head[4] = {c.th, c.tw, c.n_taps, instance};
-    put(head, sizeof head);
-    for (int i = 0; i < c.n_taps; ++i) {
-        const stx_tap &t = c.taps[i];
-        const int blob = e->find_blob(t.layer);
-        const int flags[4] = {blob, t.is_content, t.is_style, t.is_dd};
-        const double w[4] = {t.layer_weight, t.content_weight, t.style_weight, t.dd_weight};
-        put(flags, sizeof flags);
-        put(w, sizeof w);
-    }
-    return key;
-}
-
-int graph_record(stx_engine *e, TileGraph *g, const TileCall &c) {
-    TilePlan plan;
-    STX_TRY(sc_grad_prepare(e, c, plan));
-    const size_t need = (size_t)c.n_taps * 2100 *
-                        (size_t)std::max(1, e->sh->n_contents + e->sh->n_styles);
-    if (g->scalars && need > g->scalars_cap) {      // more targets than when this key was first recorded
-        STX_HIP(hipStreamSynchronize(e->stream));
-        (void)hipFree(g->scalars);
-        (void)hipFree(g->dyn);
-        (void)hipHostFree(g->scalars_host);
-        g->scalars = nullptr;
-    }
-    if (!g->scalars) {
-        g->scalars_cap = need;
-        STX_HIP(hipMalloc(reinterpret_cast<void **>(&g->scalars), g->scalars_cap * sizeof(float)));
-        STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->scalars_host),
-                              g->scalars_cap * sizeof(float), hipHostMallocDefault));
-        STX_HIP(hipMalloc(reinterpret_cast<void **>(&g->dyn), 2 * kMaxDynWindows * sizeof(int)));
-    }
-    g->destroy_graph();
-    g->windows.clear();
-    g->scalars_used = 0;
-    const unsigned long epoch = g_alloc_epoch.load();
-    e->arena_dev = g->scalars;
-    e->arena_cap = g->scalars_cap;
-    e->arena_used = &g->scalars_used;
-    e->recording = g;
-    PendingLoss pl;
-    int rc = STX_OK;
-    hipError_t err = hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed);
-    if (err == hipSuccess) {
-        rc = sc_grad_run(e, c, plan, pl, g);
-        err = hipStreamEndCapture(e->stream, &g->graph);
-    }
-    e->recording = nullptr;
-    use_own_arena(e);
-    if (err != hipSuccess) {
-        (void)hipGetLastError();
-        set_error("stream capture failed: %s", hipGetErrorString(err));
-        rc = STX_ERR_HIP;
-    }
-    if (rc == STX_OK && g_alloc_epoch.load() != epoch) {
-        set_error("device memory was reallocated while a launch graph was recorded");
-        rc = STX_ERR_STATE;
-    }
-    if (rc == STX_OK) {
-        err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-        if (err != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
-            rc = STX_ERR_HIP;
-        }
-    }
-    if (rc != STX_OK) {
-        g->destroy_graph();
-        return rc;
-    }
-    g->epoch = epoch;
-    g->terms = pl.terms;
-    g->flop_algorithmic = e->flop_algorithmic;
-    g->flop_issued = e->flop_issued;
-    ++e->n_captures;
-    return STX_OK;
-}
-
-int graph_replay(stx_engine *e, TileGraph *g, const TileCall &c, double *loss_out) {
-    // the origins of the content windows for this call (start // scale, roll // scale per layer:
-    // style_transfer.py:572,647-655), re-validated like the eager path does
-    int vals[2 * kMaxDynWindows];
-    int n = 0;
-    for (const DynWindow &w : g->windows) {
-        const int oy = (int)std::floor((double)c.start[0] / w.scale);
-        const int ox = (int)std::floor((double)c.start[1] / w.scale);
-        const int sx = (int)std::floor((double)c.rx / w.scale);
-        const int sy = (int)std::floor((double)c.ry / w.scale);
-        if (oy + w.fh > w.ch || ox + w.fw > w.cw) {
-            set_error("content window [%d+%d, %d+%d] exceeds the %dx%d map of layer %s", oy, w.fh,
-                      ox, w.fw, w.ch, w.cw, w.blob.c_str());
-            return STX_ERR_ARG;
-        }
-        vals[n++] = oy - sy;
-        vals[n++] = ox - sx;
-    }
-    if (n) STX_TRY(set_ints_launch(e->stream, g->dyn, vals, n));
-    Blob &in = e->blobs[e->layers[0].top_blob];
-    const size_t bytes = (size_t)in.channels * c.th * c.tw * sizeof(float);
-    if (c.img != in.data.ptr) STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, bytes));   // (stx_tile_buffers)
-    STX_HIP(hipEventRecord(e->ev_start, e->stream));
-    STX_HIP(hipGraphLaunch(g->exec, e->stream));
-    STX_HIP(hipEventRecord(e->ev_stop, e->stream));
-    e->timed = true;
-    e->flop_algorithmic = g->flop_algorithmic;
-    e->flop_issued = g->flop_issued;
-    if (c.grad_out != in.diff.ptr) STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, bytes));
-    PendingLoss pl;
-    pl.out = loss_out;
-    pl.terms = g->terms;
-    pl.host = g->scalars_host;
-    e->pending.push_back(std::move(pl));
-    g->in_flight = true;
-    ++e->n_replays;
+    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
+                           hipMemcpyDeviceToHost, e->stream));
     return STX_OK;
 }
 
@@ -1794,11 +1561,11 @@ int sc_grad_eager(stx_engine *e, const TileCall &c, double *loss_out) {
     if (c.img != in.data.ptr) STX_TRY(copy_in(e, in.data.ptr, c.img, c.img_mem, in.count() * sizeof(float)));
     PendingLoss pl;
     pl.out = loss_out;
-    STX_TRY(sc_grad_run(e, c, plan, pl, nullptr));
+    STX_TRY(sc_grad_run(e, c, plan, pl));
     if (c.grad_out != in.diff.ptr)
         STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, in.count() * sizeof(float)));
     e->pending.push_back(std::move(pl));
-    ++e->n_eager;
+    ++e->n_tile_evals;
     return STX_OK;
 }
 
@@ -1816,52 +1583,7 @@ int stx_sc_grad_tile(stx_engine *e, const float *img, int img_mem, int th, int t
     STX_TRY(e->set_device());
     const TileCall c{img, img_mem, th, tw, roll_xy ? roll_xy[0] : 0, roll_xy ? roll_xy[1] : 0,
                      {start_yx[0], start_yx[1]}, taps, n_taps, grad_out, grad_mem};
-    // loss terms beside the backward pass on small tiles (they cannot fill the chip on their own)
-    e->side = e->side_mode == 1 || (e->side_mode < 0 && (long)th * tw <= 512L * 512L) ? e->side2 : e->stream;
-    // Recorded launch graphs: a key's first evaluations run eagerly (they size buffers, pack
-    // filter banks and may time kernel variants -- none of which can be recorded), the next one
-    // is recorded, later ones replay the recording for as long as no device buffer moved.
-    // Pageable host memory cannot be copied from inside a recording and profiling needs its
-    // events around every launch group: those calls stay eager.
-    TileGraph *g = nullptr;
-    if (e->graphs_on && !e->profiling && e->side == e->stream && img_mem == STX_DEVICE &&
-        grad_mem == STX_DEVICE) {
-        if (e->graphs.size() > 256) {       // stale recordings of earlier scales
-            const unsigned long now = g_alloc_epoch.load();
-            for (auto it = e->graphs.begin(); it != e->graphs.end();)
-                it = (!it->second->in_flight && it->second->epoch != now) ? e->graphs.erase(it) : ++it;
-        }
-        for (int instance = 0; instance < 64; ++instance) {
-            auto &slot = e->graphs[graph_key(e, c, instance)];
-            if (!slot) slot.reset(new TileGraph);
-            if (!slot->in_flight) {
-                g = slot.get();
-                break;
-            }
-        }
-        if (g && g->disabled) g = nullptr;
-    }
-    int rc;
-    if (!g) {
-        rc = sc_grad_eager(e, c, loss_out);
-    } else {
-        const unsigned long epoch = g_alloc_epoch.load();
-        if (g->epoch != epoch) {        // buffers moved (new scale, larger tile): start over
-            g->destroy_graph();
-            g->eager_calls = 0;
-        }
-        if (!g->exec && g->eager_calls >= e->graph_min_eager) {
-            if (graph_record(e, g, c) != STX_OK) g->disabled = true;   // (stays eager; the error text is kept)
-        }
-        if (g->exec) {
-            rc = graph_replay(e, g, c, loss_out);
-        } else {
-            rc = sc_grad_eager(e, c, loss_out);
-            g->eager_calls += 1;
-            g->epoch = g_alloc_epoch.load();
-        }
-    }
-    STX_TRY(rc);
+    STX_TRY(sc_grad_eager(e, c, loss_out));
     if (sync_now) return do_sync(e);
     return STX_OK;
 }
@@ -2277,7 +1999,6 @@ int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed) {
     if (!e || (!buf && buf_len)) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     STX_HIP(hipStreamSynchronize(e->stream));
-    STX_HIP(hipStreamSynchronize(e->side2));
     std::string out;
     for (auto &pe : e->prof) {
         float ms = 0.f;

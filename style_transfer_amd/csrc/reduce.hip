@@ -154,15 +154,6 @@ __global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__
     }
 }
 
-// dst[i] = vals[i], i < n <= 16: per-call parameters of a replayed launch graph (values travel
-// as kernel arguments, so no host buffer has to outlive the call).
-struct IntPack16 {
-    int v[16];
-};
-__global__ void set_ints_kernel(int *__restrict__ dst, IntPack16 vals, int n) {
-    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
-}
-
 // The shader clock at this point of a stream (stx_clock_marks): lane 0 of ONE wave reads the core-
 // cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime), dozes for `ticks` of
 // the latter (20 us), reads both again and stores the two differences.
@@ -190,16 +181,6 @@ int clock_mark_launch(hipStream_t s, long long *out, long long ticks) {
     return STX_OK;
 }
 
-int set_ints_launch(hipStream_t s, int *dst, const int *vals, int n) {
-    for (int done = 0; done < n; done += 16) {
-        IntPack16 pack{};
-        const int m = std::min(16, n - done);
-        for (int i = 0; i < m; ++i) pack.v[i] = vals[done + i];
-        set_ints_kernel<<<1, 64, 0, s>>>(dst + done, pack, m);
-        STX_CHECK_LAUNCH();
-    }
-    return STX_OK;
-}
 
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef,

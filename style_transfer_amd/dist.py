@@ -20,8 +20,10 @@ pixel each way.  The iteration's shift (``roll``) travels in the same batch as t
 two-element message to each peer (the reference puts it into every SCGradRequest,
 ``style_transfer.py:158-161,634-637``).  Collectives run once, outside the step loop:
 ``broadcast_weights`` (the VGG filter bank, once per run) and ``broadcast_targets`` (style Grams
-and content maps, once per scale); both hand back tensors on the compute device, nothing is
-bounced through host memory.  The arithmetic is injected through callables so that the protocol
+and content maps, once per scale); both hand back tensors on the compute device.  On RCCL a
+target that already lives on rank 0's GPU (a ``DeviceArray`` or a CUDA tensor) is broadcast from
+where it lies -- a 537 MB content map of a 4096 x 4096 scale never visits host memory; host arrays
+(the small Grams) are uploaded once.  Only the gloo debug / CI wire stages through the host.  The arithmetic is injected through callables so that the protocol
 can be exercised on CPU (gloo) in the unit tests.
 """
 
@@ -141,7 +143,7 @@ class DistributedTiles:
         # ---- gather
         ops = []
         if self.rank == 0:
-            total = 0.0
+            losses = [0.0] * len(rects)
             incoming = []
             for t in range(len(rects)):
                 if owner[t] == 0:
@@ -158,12 +160,14 @@ class DistributedTiles:
             self._sync()
             for t, (loss, grad) in zip(mine, results):
                 self.put(rects[t], grad, roll)
-                total += loss
+                losses[t] = loss
             for t, gbuf in incoming:
                 self.put(rects[t], self._in(gbuf), roll)
-            for lbuf in loss_bufs.values():
-                total += float(lbuf.sum())
-            return total
+            for r, lbuf in loss_bufs.items():
+                for t, v in zip([t for t in range(len(rects)) if owner[t] == r], lbuf.tolist()):
+                    losses[t] = v
+            # added up in tile order, like the single-process farm does (the same bits)
+            return float(sum(losses))
         if mine:
             for (loss, grad) in results:
                 ops.append(dist.P2POp(dist.isend, self._out(grad), 0, self.group))
@@ -213,8 +217,9 @@ def broadcast_weights(weights, device, group=None):
 
 def broadcast_targets(contents, styles, device, group=None):
     """Broadcasts rank 0's targets (lists of {layer: array}) to every rank, once per scale.
-    Sources may be numpy arrays, torch tensors or anything with ``.get()`` (DeviceArray); the
-    result is lists of {layer: torch tensor on ``device``} -- the maps stay on the GPU."""
+    Sources may be numpy arrays, torch tensors or DeviceArrays (``__cuda_array_interface__``:
+    broadcast in place on RCCL; ``.get()`` on the gloo debug wire); the result is lists of
+    {layer: torch tensor on ``device``} -- the maps stay on the GPU."""
     rank = dist.get_rank(group)
     wire = _wire_device(device, group)
     meta = [None]
@@ -233,6 +238,10 @@ def broadcast_targets(contents, styles, device, group=None):
                     v = src[i][layer]
                     if isinstance(v, torch.Tensor):
                         t = v.to(wire, torch.float32).contiguous()
+                    elif hasattr(v, '__cuda_array_interface__') and wire.type == 'cuda':
+                        # a DeviceArray on this rank's GPU: broadcast it from where it lies
+                        v.engine.sync()             # (written on the engine's stream, read on torch's)
+                        t = torch.as_tensor(v, device=wire)
                     else:
                         v = v.get() if hasattr(v, 'get') else v
                         t = torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(wire)

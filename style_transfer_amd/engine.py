@@ -53,6 +53,13 @@ class DeviceArray:
     def size(self):
         return int(np.prod(self.shape, dtype=np.int64))
 
+    @property
+    def __cuda_array_interface__(self):
+        """Lets torch (``torch.as_tensor(arr, device=...)``) view the array without a copy, e.g.
+        as the source of an RCCL broadcast.  The caller orders the streams (``engine.sync()``)."""
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (int(self.ptr), False),
+                'version': 2, 'strides': None}
+
     def set(self, host):
         host = np.ascontiguousarray(host, self.dtype)
         assert host.shape == self.shape, (host.shape, self.shape)

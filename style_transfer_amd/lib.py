@@ -13,8 +13,8 @@ LIB_PATH = os.environ.get('STX_LIB') or os.path.join(_HERE, 'csrc', 'libstx.so')
 HOST, DEVICE = 0, 1
 LAYER_INPUT, LAYER_CONV, LAYER_RELU, LAYER_POOL = 0, 1, 2, 3
 POOL_MAX, POOL_AVE = 0, 1
-(Q_SHARED_ENGINES, Q_TARGET_UPLOADS, Q_TARGET_BYTES, Q_WEIGHT_BYTES, Q_GRAPH_CAPTURES,
- Q_GRAPH_REPLAYS, Q_EAGER_TILES) = range(7)
+(Q_SHARED_ENGINES, Q_TARGET_UPLOADS, Q_TARGET_BYTES, Q_WEIGHT_BYTES, Q_TILE_EVALS,
+ Q_PEERS_WITHOUT_ACCESS) = range(6)
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

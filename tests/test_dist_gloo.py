@@ -31,7 +31,7 @@ def _problem():
     return img, style, cl, cw, sl, sw
 
 
-def _worker(rank, world, port, out_path, two_phase=False):
+def _worker(rank, world, port, out_path, two_phase=False, tile_size=32):
     from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -77,7 +77,7 @@ def _worker(rank, world, port, out_path, two_phase=False):
         return evaluate(*pending.pop('args'))
 
     farm = DistributedTiles(cut, (begin, end) if two_phase else evaluate, put, 'cpu')
-    rects = tile_grid(img.shape[-2:], 32)
+    rects = tile_grid(img.shape[-2:], tile_size)
     # only rank 0 knows the shift; it reaches rank 1 with the tiles, not through a collective
     loss = farm.eval_sc_grad(rects, roll if rank == 0 else None)
     if rank == 0:
@@ -100,4 +100,25 @@ def test_two_rank_tile_farm_equals_single_process(tmp_path, two_phase):
     ref_loss, ref_grad = om.sc_grad(roll_xy(img.copy(), roll), roll, 32, cl, sl, {}, cw, sw)
     assert int(got['n_tiles']) == 6
     assert float(got['loss']) == pytest.approx(ref_loss, rel=1e-12)
+    assert np.array_equal(got['grad'], ref_grad)
+
+
+@pytest.mark.timeout(600)
+def test_strong_layout_with_an_idle_rank_equals_single_process(tmp_path):
+    """bench.py's strong layout at N = 8 has more ranks than tiles (four tiles of the fixed
+    2048 x 2048 image, eight GPUs): ranks without a tile take part in nothing but the barriers.
+    Here: two tiles, three ranks -- rank 2 owns no tile, receives no header and sends nothing; the
+    stitched result equals the single-process evaluation bit for bit and the loss is added up in
+    tile order."""
+    out = str(tmp_path / 'dist3.npz')
+    mp.spawn(_worker, args=(3, _free_port(), out, True, 48), nprocs=3, join=True)
+    got = np.load(out)
+    img, style, cl, cw, sl, sw = _problem()
+    om, _ = make_oracle('vgg16_avgpool')
+    om.styles = [om.style_grams([style], sl, 512)]
+    om.contents = [om.prepare_features(img, cl, 512)]
+    roll = (16, -8)
+    ref_loss, ref_grad = om.sc_grad(roll_xy(img.copy(), roll), roll, 48, cl, sl, {}, cw, sw)
+    assert int(got['n_tiles']) == 2
+    assert float(got['loss']) == ref_loss
     assert np.array_equal(got['grad'], ref_grad)

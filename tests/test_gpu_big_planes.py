@@ -41,7 +41,6 @@ def test_big_addressing_variants_are_bit_identical(model, th, tw, monkeypatch):
     results = []
     for big in ('0', '1'):
         monkeypatch.setenv('STX_WINO_BIG', big)
-        monkeypatch.setenv('STX_GRAPH', '0')
         eng = TileEngine(net, 0, weights)
         r = np.random.RandomState(7)
         eng.set_contents_and_styles(

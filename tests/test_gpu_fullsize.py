@@ -80,32 +80,6 @@ def test_sc_grad_tile_at_benchmark_sizes(th, tw, ih, iw, start, roll):
     assert stats['tainted'] < MAX_TAINTED, stats
 
 
-@pytest.mark.parametrize('th,tw,ih,iw,start,roll', TILE_CASES[:2])
-def test_sc_grad_tile_with_the_bf16_three_piece_convolution(th, tw, ih, iw, start, roll, monkeypatch):
-    """STX_CONV_BF3=1 (off by default): the plain 3x3 layers from 128 input
-    channels up run on the bf16 matrix cores -- 1-D Winograd, operands split into three bf16 pieces,
-    six exact products per pair (csrc/conv_bf3.hip).  Same bounds as the fp32 kernels: activations,
-    loss and gradient at 1e-5 of max, no more decision flips."""
-    om, _ = make_oracle('vgg19')
-    eng = gpu_engine('vgg19')
-    rng = np.random.RandomState(th + tw)
-    cl, cw = normalized_weights(['conv4_2'], 0.05)
-    sl, sw = normalized_weights(DEFAULT_STYLE_LAYERS, 1)
-    om.contents, om.styles = _random_targets(om, rng, (ih, iw), cl, sl)
-    eng.set_contents_and_styles(om.contents, om.styles)
-    tile = _smooth(rng, th, tw)
-    eng.sc_grad_tile(tile, start, roll, cl, sl, {}, cw, sw)
-    issued_fp32 = eng.last_tile_flops()[1]
-    monkeypatch.setenv('STX_CONV_BF3', '1')
-    _, _, stats = check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, {}, blas_loss_tol=5e-4)
-    issued = eng.last_tile_flops()[1]
-    print('%dx%d tile, bf16x3 convolutions: %s, issued %.3f of the fp32 path\'s matrix time'
-          % (th, tw, stats, issued / issued_fp32))
-    assert issued < 0.9 * issued_fp32               # (the switch took: those layers count 0.25 of direct)
-    assert stats['relu_flips'] + stats['pool_flips'] < MAX_FLIPS_PER_MPIXEL * th * tw / 2 ** 20, stats
-    assert stats['tainted'] < MAX_TAINTED, stats
-
-
 def test_sc_grad_tile_vgg16_avgpool_at_1024():
     """Config 5's network at the benchmark tile size, two style targets (averaged Grams are the
     host's business; the engine sees n_styles = 2 separate sets)."""

@@ -8,12 +8,11 @@
 #   3. FETCH_SIZE and WRITE_SIZE passes over bench.py (HBM traffic per tile-iteration)
 # Counters are collected in runs of their own, with --kernel-trace only (MI355X_MICROARCH.md).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-export STX_GRAPH=0     # every kernel its own dispatch (the recorded graphs replay the same kernels)
 BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-wall-clock --steady-seconds 0"
 TILE="python $R/tools/bench_tile.py 1024 7"
 find_csv() { find "$1" -name "*_$2.csv" | head -1; }

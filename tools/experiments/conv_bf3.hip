@@ -35,8 +35,26 @@
 #include <cstdlib>
 #include <type_traits>
 
+// (round 4: moved out of libstx.so; compile with -DSTX_EXPERIMENT_BF3, which restores the two
+// fields of ConvProblem / WinoArgs this kernel used; tools/ubench/bf3conv_bench.hip does)
+#ifndef STX_EXPERIMENT_BF3
+#error "compile with -DSTX_EXPERIMENT_BF3"
+#endif
 #include "bf16x3.h"
 #include "common.h"
+
+namespace stx {
+// 1-D Winograd on the bf16 matrix cores with three-piece operands (conv_bf3.hip); config id 300.
+ConvConfig bf3_config();
+size_t bf3_packed_floats(int K, int M);
+int bf3_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed);
+int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+bool bf3_usable(const ConvProblem &p);      // what the kernel takes (shape, epilogue, addressing)
+// The pre-split form: bf3_split_launch writes the transformed, three-piece operand of a whole layer
+// once (bf3_split_bytes of scratch), bf3_launch with p.x_split set reads it instead of p.x.
+size_t bf3_split_bytes(int K, int H, int W);
+int bf3_split_launch(hipStream_t s, const float *x, int K, int H, int W, void *split);
+}  // namespace stx
 
 #ifndef STX_BF3_HILO
 #define STX_BF3_HILO 0   // 1: the five small products of a step go into accumulators of their own

@@ -1,8 +1,8 @@
 """Per-scale cost of the step loop: ms per optimizer step at the single-tile and multi-tile
 scales of the `--size 2048 --tile-size 1024` pyramid, through TileFarm (the product path), with
-the GPU span of the tile evaluation (HIP events) and the launch-graph counters beside it.
+the GPU span of the tile evaluation (HIP events) and the host's queueing cost beside it.
 
-    python tools/scale_steps.py [sizes...]       STX_GRAPH=0 turns the recorded graphs off
+    python tools/scale_steps.py [sizes...]
 """
 import os
 import sys
@@ -25,7 +25,6 @@ net = builtin_net('vgg19')
 farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
 eng = farm.master
 rng = np.random.RandomState(0)
-print('graphs %s' % os.environ.get('STX_GRAPH', '1'))
 for size in sizes:
     img_host = rng.uniform(-110, 120, (3, size, size)).astype(np.float32)
     contents = [farm.prepare_features_device(img_host, CL, 1024, passes=1)]
@@ -63,9 +62,8 @@ for size in sizes:
         farm.eval_sc_grad(img, grad, roll, CL, SL, {}, CW, SW, 1024, lazy=True)
     queue = (time.perf_counter() - t1) / 20 * 1e3
     eng.sync()
-    print('size %4d: %7.3f ms/step, tile span %7.3f ms, queueing eval_sc_grad %6.3f ms; replays %d eager %d'
-          % (size, dt, gpu, queue, sum(e.query(lib.Q_GRAPH_REPLAYS) for e in farm.engines),
-             sum(e.query(lib.Q_EAGER_TILES) for e in farm.engines)), flush=True)
+    print('size %4d: %7.3f ms/step, tile span %7.3f ms, queueing eval_sc_grad %6.3f ms; tile evaluations %d'
+          % (size, dt, gpu, queue, sum(e.query(lib.Q_TILE_EVALS) for e in farm.engines)), flush=True)
     for a in (img, grad, old):
         a.free()
 farm.close()

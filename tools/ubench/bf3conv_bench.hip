@@ -1,9 +1,9 @@
 // Standalone timing + accuracy harness for conv_bf3.hip (tuning aid, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I style_transfer_amd/csrc \
-//         [-DSTX_BF3_TIMING] [-DSTX_BF3_SKIP=7] tools/ubench/bf3conv_bench.hip -o build_ubench/bf3conv_bench
+//         -DSTX_EXPERIMENT_BF3 [-DSTX_BF3_TIMING] [-DSTX_BF3_SKIP=7] tools/ubench/bf3conv_bench.hip -o build_ubench/bf3conv_bench
 // Prints, per shape, the time of the kernel and its error against a float64 direct convolution
 // on a sample of output channels (max |err| / max |ref|).
-#include "../../style_transfer_amd/csrc/conv_bf3.hip"
+#include "../experiments/conv_bf3.hip"
 
 #include <cstdarg>
 #include <vector>
