@@ -56,12 +56,25 @@ class Progress:
         self.writer = ThreadPoolExecutor(max_workers=1) if save_every else None
         self.writes = []
 
-    def finish(self):
-        """Waits for the --save-every pictures still being encoded."""
+    MAX_PENDING_WRITES = 4      # frames (H x W x 3 bytes each) waiting for the encoder thread
+
+    def finish(self, reraise=True):
+        """Waits for the --save-every pictures still being encoded.  Writer errors are reported;
+        they are raised only when no other exception is already on its way (``reraise``)."""
+        errors = []
         for w in self.writes:
-            w.result()
+            try:
+                w.result()
+            except Exception as err:    # pylint: disable=broad-except
+                errors.append(err)
+        self.writes = []
         if self.writer is not None:
             self.writer.shutdown()
+        for err in errors:
+            print('--save-every: writing a picture failed: %s: %s' % (type(err).__name__, err),
+                  file=sys.stderr)
+        if errors and reraise:
+            raise errors[0]
 
     def set_steps(self, steps):
         self.steps = steps
@@ -78,6 +91,9 @@ class Progress:
         if self.save_every and self.step % self.save_every == 0:
             # the pixels leave the GPU now; deflate and file I/O run beside the next steps
             rgb = image_ops.to_u8(transfer.engine, transfer.current_raw, transfer.mean)
+            self.writes = [w for w in self.writes if not w.done() or w.exception() is not None]
+            while sum(not w.done() for w in self.writes) >= self.MAX_PENDING_WRITES:
+                next(w for w in self.writes if not w.done()).exception()     # (waits for it)
             self.writes.append(self.writer.submit(fastpng.save_rgb,
                                                   self.run + '_out_%04d.png' % self.step, rgb))
         print('Step %d, time: %.2f s, update: %.2f, loss: %e, tv: %.2f' %
@@ -111,34 +127,50 @@ def main(argv=None):
         for layer, shape in net.shapes().items():
             print('% 25s %s' % (layer, shape))
         return 0
-    # The weight file is read (or the seeded bank drawn) on a helper thread while this one wakes
-    # the GPU runtime up and decodes the pictures: all three release the interpreter lock.
-    loader = ThreadPoolExecutor(max_workers=1)
-    weights_future = loader.submit(load_weights, args.weights, net)
-    n_gpus = lib.device_count()
-    if n_gpus < 1:
-        raise RuntimeError('no AMD GPU visible: this engine has no CPU path')
+    # Three things run side by side, each releasing the interpreter lock: the weight file is read
+    # (or the seeded bank drawn) on one helper thread, the GPU runtime is woken up and the engines
+    # (streams, scalar arenas) are created on another, and this thread decodes the pictures.
+    if any(d < 0 for d in args.devices):
+        # the reference runs device -1 as a Caffe-CPU worker (config_system.py:56,
+        # style_transfer.py:193-201); there is no CPU path here, by design
+        print('--devices -1 (CPU worker) is mapped to GPU 0: this engine has no CPU path.')
     devices = [d if d >= 0 else 0 for d in args.devices]
-    print('Initializing %s on device(s) %s.' % (args.weights, devices))
-    content_image = Image.open(args.content_image).convert('RGB')
-    style_images = [Image.open(p).convert('RGB') for p in args.style_images]
-    initial_image = Image.open(args.init_image).convert('RGB') if args.init_image else None
-    aux_image = Image.open(args.aux_image).convert('RGB') if args.aux_image else None
-    weights = weights_future.result()
-    loader.shutdown()
-    farm = TileFarm(net, devices, weights)
+
+    def wake_gpus():
+        if lib.device_count() < 1:
+            raise RuntimeError('no AMD GPU visible: this engine has no CPU path')
+        return TileFarm(net, devices, None)
+
+    loader = ThreadPoolExecutor(max_workers=2)
+    weights_future = loader.submit(load_weights, args.weights, net)
+    farm_future = loader.submit(wake_gpus)
+    try:
+        print('Initializing %s on device(s) %s.' % (args.weights, devices))
+        content_image = Image.open(args.content_image).convert('RGB')
+        style_images = [Image.open(p).convert('RGB') for p in args.style_images]
+        initial_image = Image.open(args.init_image).convert('RGB') if args.init_image else None
+        aux_image = Image.open(args.aux_image).convert('RGB') if args.aux_image else None
+        farm = farm_future.result()
+        farm.set_weights(weights_future.result())
+    finally:
+        # (an error above must not wait for 80 MB of weights nobody will use)
+        weights_future.cancel()
+        loader.shutdown(wait=False)
     transfer = StyleTransfer(farm, args, state)
     stats = StatLogger()
     progress = Progress(run, stats, args.save_every)
     np.random.seed(args.seed)
+    failed = True
     try:
         transfer.transfer_multiscale([content_image], style_images, initial_image, aux_image,
                                      callback=progress)
+        failed = False
     except (EOFError, KeyboardInterrupt):
         print()
+        failed = False
     finally:
         stats.dump(run + '_log.csv')
-        progress.finish()
+        progress.finish(reraise=not failed)
     if transfer.current_raw is not None:
         path = args.output_image or run + '_out.png'
         print('Saving output as %s.' % path)

@@ -680,6 +680,7 @@ struct SmallConvArgs {
     float *y;            // [M][H][W], M <= 4
     const float *mask;   // optional [M][H][W]
     int K, M, H, W, n_chunks, tiles_x, x_bytes, w_bytes;
+    int n_wg, wg_per_xcd;   // patches of the plane; patches per XCD (work order, see the kernel)
 };
 
 // VEC (plane width a multiple of 4, 16-byte aligned planes): the 64 interior columns of a patch
@@ -696,12 +697,20 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     constexpr int NVT = (NV + NT - 1) / NT;
     constexpr int NH = KC * XR * 2;                                 // halo dwords per chunk (VEC)
     static_assert(W_FLOATS / 4 <= NT, "one float4 of weights per thread");
-    static_assert(NH <= NT, "one halo element per thread");
+    constexpr int NHT = (NH + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float Xl[X_FLOATS];
     __shared__ __attribute__((aligned(16))) float Wl[W_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int y0 = sgpr((blockIdx.x / a.tiles_x) * PR), x0 = sgpr((blockIdx.x % a.tiles_x) * PC);
+    // Work order.  Workgroup b of a launch runs on XCD b mod 8 (tools/ubench/xcc_map.hip), and each
+    // XCD has its own L2: with patches dealt out in launch order the two halo columns of a patch
+    // row (one dword each, but a whole cache line of the neighbouring patch) and its two halo rows
+    // were fetched by an XCD that never saw the neighbour -- 556 MB fetched for 268 MB of input by
+    // PMC (profiles/r03: 2.07x).  Every XCD takes a contiguous band of patch rows instead, in
+    // raster order, so that a halo line is in the L2 the neighbour just pulled it through.
+    const int patch = sgpr((int)(blockIdx.x & 7) * a.wg_per_xcd + (int)(blockIdx.x >> 3));
+    if (patch >= a.n_wg) return;
+    const int y0 = sgpr((patch / a.tiles_x) * PR), x0 = sgpr((patch % a.tiles_x) * PC);
     const int HW = a.H * a.W;
     constexpr unsigned kOob = 0x80000000u;
     // x_bytes == 0: a plane set of 2 GiB or more -- the descriptor is moved to each chunk's KC
@@ -711,8 +720,8 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
         const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
-    unsigned xvoff[VEC ? 1 : NX], vvoff[VEC ? NVT : 1], hvoff = kOob;
-    int vdst[VEC ? NVT : 1], hdst = 0;
+    unsigned xvoff[VEC ? 1 : NX], vvoff[VEC ? NVT : 1], hvoff[NHT];
+    int vdst[VEC ? NVT : 1], hdst[NHT];
     if (VEC) {
 #pragma unroll
         for (int n = 0; n < NVT; ++n) {
@@ -725,13 +734,15 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
             vvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
             vdst[n] = e < NV ? (ci * XR + r) * XC + X0 + 1 + 4 * c4 : -1;
         }
-        if (tid < NH) {
-            const int ci = tid / (XR * 2), rem = tid - ci * (XR * 2);
+#pragma unroll
+        for (int n = 0; n < NHT; ++n) {
+            const int e = tid + n * NT;
+            const int ci = e / (XR * 2), rem = e - ci * (XR * 2);
             const int r = rem >> 1, side = rem & 1;
             const int yy = y0 - 1 + r, xx = side ? x0 + PC : x0 - 1;
-            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            hvoff = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
-            hdst = (ci * XR + r) * XC + X0 + (side ? PC + 1 : 0);
+            const bool ok = e < NH && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            hvoff[n] = ok ? (unsigned)(ci * HW + yy * a.W + xx) * 4u : kOob;
+            hdst[n] = e < NH ? (ci * XR + r) * XC + X0 + (side ? PC + 1 : 0) : -1;
         }
     } else {
 #pragma unroll
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
         }
     }
     const unsigned wvoff = tid < W_FLOATS / 4 ? (unsigned)tid * 16u : kOob;
-    unsigned xreg[VEC ? 1 : NX], hreg = 0;
+    unsigned xreg[VEC ? 1 : NX], hreg[NHT];
     u32x4 vreg[VEC ? NVT : 1];
     u32x4 wreg;
     auto load_stage = [&](int chunk) {
@@ -761,7 +772,8 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
         if (VEC) {
 #pragma unroll
             for (int n = 0; n < NVT; ++n) vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, vvoff[n], xs, 0);
-            hreg = __builtin_amdgcn_raw_buffer_load_b32(rx, hvoff, xs, 0);
+#pragma unroll
+            for (int n = 0; n < NHT; ++n) hreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, hvoff[n], xs, 0);
         } else {
 #pragma unroll
             for (int n = 0; n < NX; ++n) xreg[n] = __builtin_amdgcn_raw_buffer_load_b32(rx, xvoff[n], xs, 0);
@@ -773,7 +785,9 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NVT; ++n)
                 if (vdst[n] >= 0) *reinterpret_cast<u32x4 *>(Xl + vdst[n]) = vreg[n];
-            if (tid < NH) reinterpret_cast<unsigned *>(Xl)[hdst] = hreg;
+#pragma unroll
+            for (int n = 0; n < NHT; ++n)
+                if (hdst[n] >= 0) reinterpret_cast<unsigned *>(Xl)[hdst[n]] = hreg[n];
         } else {
 #pragma unroll
             for (int n = 0; n < NX; ++n) {
@@ -830,7 +844,7 @@ __global__ __launch_bounds__(256) void conv3x3_m4_kernel(SmallConvArgs a) {
     }
 }
 
-constexpr int kSmallKC = 8, kSmallPR = 8;
+constexpr int kSmallKC = 8, kSmallPR = 16;
 
 size_t conv_small_packed_floats(int K) { return (size_t)ceil_div(K, kSmallKC) * kSmallKC * 9 * 4; }
 
@@ -885,13 +899,23 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
     a.tiles_x = ceil_div(W, 64);
     a.x_bytes = big ? 0 : (int)xb;
     a.w_bytes = (int)(conv_small_packed_floats(K) * 4);
-    const int n_wg = a.tiles_x * ceil_div(H, kSmallPR);
     // 16-byte loads need 16-byte aligned rows: plane width a multiple of 4, aligned base
     const char *novec = getenv("STX_SMALL_NOVEC");
-    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !(novec && atoi(novec)))
-        conv3x3_m4_kernel<kSmallKC, kSmallPR, true><<<n_wg, 256, 0, s>>>(a);
-    else
-        conv3x3_m4_kernel<kSmallKC, kSmallPR, false><<<n_wg, 256, 0, s>>>(a);
+    const bool vec = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !(novec && atoi(novec));
+    // 16-row patches (10 % of halo rows, 0.75 LDS reads per MFMA) where the plane still yields a
+    // few workgroups per CU; 8-row patches (25 %, 1.2) on small planes
+    const bool tall = (long)a.tiles_x * ceil_div(H, kSmallPR) >= 1024;
+    const int pr = tall ? kSmallPR : kSmallPR / 2;
+    a.n_wg = a.tiles_x * ceil_div(H, pr);
+    a.wg_per_xcd = ceil_div(a.n_wg, 8);
+    const int grid = a.wg_per_xcd * 8;
+    if (tall) {
+        if (vec) conv3x3_m4_kernel<kSmallKC, kSmallPR, true><<<grid, 256, 0, s>>>(a);
+        else conv3x3_m4_kernel<kSmallKC, kSmallPR, false><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (vec) conv3x3_m4_kernel<kSmallKC, kSmallPR / 2, true><<<grid, 256, 0, s>>>(a);
+        else conv3x3_m4_kernel<kSmallKC, kSmallPR / 2, false><<<grid, 256, 0, s>>>(a);
+    }
     STX_CHECK_LAUNCH();
     return STX_OK;
 }

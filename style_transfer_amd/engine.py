@@ -186,8 +186,13 @@ class TileEngine:
 
     def keep_until_sync(self, result):
         """Holds a reference to an object the library will write into at the next sync (a
-        pending loss): it must not be collected before, even if its owner lets go of it."""
+        pending loss): it must not be collected before, even if its owner lets go of it.  The
+        library publishes pending values whenever it drains its scalar arena, also inside calls
+        that never come back through ``sync()``; the list is bounded so that such callers cannot
+        grow it without limit (an entry older than 4096 evaluations has long been published)."""
         self._results.append(result)
+        if len(self._results) > 4096:
+            del self._results[:2048]
         return result
 
     def wait_for(self, other):

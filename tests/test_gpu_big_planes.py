@@ -152,3 +152,34 @@ def test_sc_grad_tile_2944():
     print('2944x2944 tile: %s, %.2f ms on the GPU' % (stats, eng.last_tile_ms()))
     assert stats['relu_flips'] + stats['pool_flips'] < 500 * th * tw / 2 ** 20, stats
     assert stats['tainted'] < 0.3, stats
+
+
+def test_sc_grad_tile_past_2gib_shallow_taps():
+    """Un-gated whole-tile case past the 32-bit addressing limit: a 2896 x 2912 tile (8.43 M
+    pixels: its 64-channel conv1_x plane sets are 2.16 GB each) through stx_sc_grad_tile with the
+    content tap at conv2_2 and style taps at conv1_1 / conv2_1, so that the oracle runs four
+    convolution layers instead of sixteen and finishes in well under a minute.  Everything that
+    has a >= 2 GiB form is on this path: conv_wino2's re-based descriptors forward and backward
+    (conv1_2, mask, fused pooling), the 64-bit-indexed Gram and the BIG SYMM of conv1_1, the
+    size_t pooling, the first layer and the backward pass into the image.  Same bounds as every
+    other tile case (tests/gpu_helpers.check_tile).  Reference: style_transfer.py:556-612,619-632
+    (any --tile-size is accepted)."""
+    om, _ = make_oracle('vgg19')
+    eng = gpu_engine('vgg19')
+    rng = np.random.RandomState(12)
+    th, tw = 2896, 2912
+    assert 64 * th * tw * 4 >= 2 ** 31
+    cl, cw = normalized_weights(['conv2_2'], 0.05)
+    sl, sw = normalized_weights(['conv1_1', 'conv2_1'], 1)
+    contents = {l: np.abs(rng.standard_normal((om.channels[l], -(-th // om.scale[l]) + 3, -(-tw // om.scale[l]) + 5))).astype(np.float32)
+                for l in cl}
+    styles = {l: np.tril(0.05 * rng.standard_normal((om.channels[l],) * 2)).astype(np.float32) for l in sl}
+    om.contents, om.styles = [contents], [styles]
+    eng.set_contents_and_styles(om.contents, om.styles)
+    coarse = rng.uniform(-110, 120, (3, th // 16 + 2, tw // 16 + 2)).astype(np.float32)
+    tile = np.repeat(np.repeat(coarse, 16, axis=1), 16, axis=2)[:, :th, :tw]
+    tile = np.ascontiguousarray(tile + rng.uniform(-16, 16, (3, th, tw)).astype(np.float32))
+    _, _, stats = check_tile(eng, om, tile, (4, 8), (-1000, 344), cl, cw, sl, sw, {}, blas_loss_tol=5e-4)
+    print('%dx%d tile, taps up to conv2_2: %s, %.2f ms on the GPU' % (th, tw, stats, eng.last_tile_ms()))
+    assert stats['relu_flips'] + stats['pool_flips'] < 500 * th * tw / 2 ** 20, stats
+    assert stats['tainted'] < 0.3, stats
