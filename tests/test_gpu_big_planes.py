@@ -179,7 +179,10 @@ def test_sc_grad_tile_past_2gib_shallow_taps():
     coarse = rng.uniform(-110, 120, (3, th // 16 + 2, tw // 16 + 2)).astype(np.float32)
     tile = np.repeat(np.repeat(coarse, 16, axis=1), 16, axis=2)[:, :th, :tw]
     tile = np.ascontiguousarray(tile + rng.uniform(-16, 16, (3, th, tw)).astype(np.float32))
-    _, _, stats = check_tile(eng, om, tile, (4, 8), (-1000, 344), cl, cw, sl, sw, {}, blas_loss_tol=5e-4)
+    # (the loss is held to 1e-5 of the float64 value of the reference's formula; against the oracle's
+    # own float32 result only to 5e-3: its BLAS sdot over the 2.7e8 elements of conv2_2 at this size
+    # is off by 2.1e-3 -- measured here: GPU 2.91983468e10, float64 2.91983470e10, float32 2.9136e10)
+    _, _, stats = check_tile(eng, om, tile, (4, 8), (-1000, 344), cl, cw, sl, sw, {}, blas_loss_tol=5e-3)
     print('%dx%d tile, taps up to conv2_2: %s, %.2f ms on the GPU' % (th, tw, stats, eng.last_tile_ms()))
     assert stats['relu_flips'] + stats['pool_flips'] < 500 * th * tw / 2 ** 20, stats
     assert stats['tainted'] < 0.3, stats
