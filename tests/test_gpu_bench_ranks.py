@@ -110,3 +110,62 @@ def test_farm_leg_child_process_prints_its_record():
     rec = _line(proc.stdout)
     assert rec['unit'] == 'tile-iterations/s' and rec['value'] > 0 and rec['steps'] == 2
     assert rec['tile_evals'] == 4 * 3 + 8 and rec['bit_identical'] is True     # (+ the identity check's two evaluations)
+
+
+def _single_rank_rccl(out_path):
+    """Child process: a one-rank RCCL group on GPU 0 next to libstx in the same process."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from style_transfer_amd.dist import DistributedTiles, broadcast_targets, broadcast_weights
+    from style_transfer_amd.engine import TileEngine
+    from style_transfer_amd.netspec import builtin_net
+    from style_transfer_amd.weights import synthetic_weights
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    net = builtin_net('vgg19')
+    host_bank = synthetic_weights(net, 0)
+    bank = broadcast_weights(host_bank, device)
+    eng = TileEngine(net, 0, bank)
+    rng = np.random.RandomState(0)
+    cmap = eng.to_device(np.abs(rng.standard_normal((512, 16, 24))).astype(np.float32))
+    gram = np.tril(rng.standard_normal((64, 64))).astype(np.float32)
+    contents, styles = broadcast_targets([{'conv4_2': cmap}], [{'conv1_1': gram}], device)
+    t = contents[0]['conv4_2']
+    result = {'in_place': bool(t.is_cuda and t.data_ptr() == cmap.ptr),
+              'content_equal': bool(np.array_equal(t.cpu().numpy(), cmap.get())),
+              'gram_equal': bool(np.array_equal(styles[0]['conv1_1'].cpu().numpy(), gram)),
+              'weights_equal': all(bool(np.array_equal(bank[k][0].cpu().numpy(), np.asarray(host_bank[k][0])))
+                                   for k in host_bank)}
+    # the tile protocol with a single rank: every tile is local, nothing is sent
+    calls = []
+    tiles = DistributedTiles(lambda rect, roll: torch.zeros((3, rect[1] - rect[0], rect[3] - rect[2]), device=device),
+                             lambda jobs, roll: [(1.5, tile) for tile, _ in jobs],
+                             lambda rect, g, roll: calls.append(rect), device)
+    result['loss'] = tiles.eval_sc_grad([(0, 8, 0, 8), (0, 8, 8, 16)], (8, 16))
+    result['puts'] = len(calls)
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+    with open(out_path, 'w') as f:
+        json.dump(result, f)
+
+
+def test_single_rank_rccl_group_broadcasts_device_targets_in_place(tmp_path):
+    """RCCL (torch.distributed backend 'nccl') initialises next to libstx in one process, and
+    dist.broadcast_targets hands a DeviceArray to the collective WHERE IT LIES: the tensor that
+    goes on the wire has the DeviceArray's own address (no bounce through host memory -- a
+    537 MB content map at a 4096 x 4096 scale).  One rank is what a one-GPU box can run; the
+    multi-rank protocol is covered on CPU by tests/test_dist_gloo.py."""
+    out = str(tmp_path / 'rccl.json')
+    code = 'import sys; sys.path.insert(0, %r); from tests.test_gpu_bench_ranks import _single_rank_rccl; ' \
+           '_single_rank_rccl(%r)' % (REPO, out)
+    proc = subprocess.run([sys.executable, '-c', code], cwd=REPO, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    got = json.load(open(out))
+    assert got == {'in_place': True, 'content_equal': True, 'gram_equal': True, 'weights_equal': True,
+                   'loss': 3.0, 'puts': 2}, got
