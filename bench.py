@@ -185,10 +185,28 @@ class FarmJob:
         self.clock = None
         self.tiles_per_step = rows * cols
         self.tiles_per_gpu = -(-self.tiles_per_step // len(set(devices)))
+        # Adam: the host queues iteration i + 1 before it collects the loss and the statistics of
+        # iteration i (StyleTransfer.transfer does the same: a fence per iteration); L-BFGS has a
+        # host decision inside its step and stays synchronous
+        self.run_ahead = optimizer == 'adam' and os.environ.get('STX_RUN_AHEAD', '1') != '0'
+        self.in_flight = None
+        self.last_loss = None
+
+    def _finish(self, item):
+        loss, stats = item
+        self.last_loss = float(loss)          # waits for that iteration's fences only
+        stats.values()
+        self.group_ms.append(max(e.last_tile_ms() for e in self.farm.engines[:self.tiles_per_step]))
+
+    def drain(self):
+        if self.in_flight is not None:
+            self._finish(self.in_flight)
+            self.in_flight = None
+        return self.last_loss
 
     def step(self):
-        """One iteration of the reference's step loop (style_transfer.py:771-815); one host
-        synchronisation, for the step statistics."""
+        """One iteration of the reference's step loop (style_transfer.py:771-815).  Returns the
+        loss of the newest FINISHED iteration (run-ahead: the previous one; drain() the last)."""
         roll = draw_roll(self.rng, self.H, self.W)
 
         def opfunc(params):
@@ -198,16 +216,26 @@ class FarmJob:
                                                  6.0), self.eng)
             return loss, self.grad
         avg, loss = self.opt.update(opfunc)
+        if self.run_ahead:
+            stats = self.image_ops.step_stats_async(self.eng, avg, self.old)
+            loss.seal(also=[self.eng])
+            previous, self.in_flight = self.in_flight, (loss, stats)
+            if previous is not None:
+                self._finish(previous)
+            return self.last_loss
         self.image_ops.step_stats(self.eng, avg, self.old)
-        loss = float(loss)
+        self.last_loss = float(loss)
         self.group_ms.append(max(e.last_tile_ms() for e in self.farm.engines[:self.tiles_per_step]))
-        return loss
+        return self.last_loss
 
     def fence(self):
+        self.drain()
         for e in self.farm.engines:
             e.sync()
 
     def timed(self, steps, warmup, clock_marks=False):
+        """W untimed iterations, everything finished; then exactly K iterations, all of them
+        finished (losses collected, every engine synchronised) when the clock stops."""
         for _ in range(warmup):
             self.step()
         self.fence()
@@ -219,10 +247,10 @@ class FarmJob:
             e.clock_marks(True)
         evals0 = self.farm.tile_evals
         t0 = time.perf_counter()
-        loss = None
         for _ in range(steps):
-            loss = self.step()
+            self.step()
         self.fence()
+        loss = self.last_loss
         elapsed = time.perf_counter() - t0
         self.timed_tile_evals = self.farm.tile_evals - evals0
         if clock_marks:

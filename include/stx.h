@@ -90,6 +90,17 @@ int stx_set_conv_weights(stx_engine *e, const char *conv_layer, const float *wei
                          const float *bias, int mem);
 /* Waits for all work queued on the engine, then writes pending loss values. */
 int stx_sync(stx_engine *e);
+/* A step loop that runs AHEAD of the GPU.  The reference's loop blocks on every iteration's loss
+ * and statistics before it starts the next one (style_transfer.py:799-815: resp_q.get(), then the
+ * callback); here the host may queue iteration i + 1 first and collect iteration i afterwards.
+ * stx_fence closes the engine's current set of pending loss values behind an event on its stream
+ * and returns a ticket; calls queued after it collect theirs in a second set.  stx_fence_wait
+ * waits for that event only -- not for the work queued since -- and writes the values of the set
+ * the ticket names (a ticket that was already published, by stx_sync or because its set had to
+ * be reused, is a no-op).  At most one closed set exists per engine: a second stx_fence before
+ * the first was waited for publishes the older set itself (after waiting for it). */
+int stx_fence(stx_engine *e, unsigned long long *ticket);
+int stx_fence_wait(stx_engine *e, unsigned long long ticket);
 /* Orders e's stream behind everything queued so far on other's stream (an event; no host wait).
  * The engines may sit on different GPUs.  This is what replaces the reference's blocking
  * resp_q.get() between handing out tiles and stitching their gradients (style_transfer.py:
@@ -290,6 +301,12 @@ int stx_vec_scale_dev(stx_engine *e, double c, const double *den_dev, double den
  * differences; then old <- avg.  Synchronous (returns after the values are on the host). */
 int stx_image_step_stats(stx_engine *e, const float *avg, float *old, int H, int W,
                          double stats[2]);
+/* The same kernel without the host wait: raw_sums[0] = sum|avg - old|, raw_sums[1] = sum(xdiff^2 +
+ * ydiff^2) over the 3*H*W elements are written (host doubles) when the engine's pending values are
+ * published -- stx_sync, or stx_fence_wait on a later fence; the caller divides by 3*H*W and
+ * takes the root (style_transfer.py:808-812). */
+int stx_image_step_stats_async(stx_engine *e, const float *avg, float *old, int H, int W,
+                               double raw_sums[2]);
 
 /* get_image (style_transfer.py:378-386): out_rgb_u8[H][W][3] = uint8(clip(img + mean, 0, 255))
  * with BGR->RGB flip and truncation toward zero.  out is STX_DEVICE memory. */
@@ -332,9 +349,10 @@ int stx_op_content_terms(stx_engine *e, const float *feat, int channels, int h, 
 int stx_profile_enable(stx_engine *e, int on);
 int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed);
 
-/* Timing: ms spent by the GPU between the first and last kernel of the most recent
- * stx_sc_grad_tile / stx_features_tile on this engine (HIP events on the engine stream);
- * valid after stx_sync. */
+/* Timing: ms spent by the GPU between the first and last kernel of the most recent FINISHED
+ * stx_sc_grad_tile / stx_features_tile on this engine (HIP events on the engine stream; after
+ * stx_sync that is the last call; while the host runs ahead it is the newest of the last four
+ * that has completed, and only if none has does the call wait, for the newest). */
 int stx_last_tile_ms(stx_engine *e, float *ms);
 
 /* Matrix-core work of the convolutions of the same call: `algorithmic` counts every layer as a

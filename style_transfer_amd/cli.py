@@ -79,6 +79,12 @@ class Progress:
     def set_steps(self, steps):
         self.steps = steps
 
+    def wants_image(self, n):
+        """Will the callback for the n-th iteration of the run (1-based) read that iteration's
+        image?  (StyleTransfer.transfer runs one iteration ahead of the GPU and calls back one
+        iteration late -- except where the answer is yes.)"""
+        return bool(self.save_every) and n % self.save_every == 0
+
     def __call__(self, step, update_size, loss, tv_loss, transfer):
         now = time.perf_counter()
         self.step += 1

@@ -138,7 +138,12 @@ struct stx_engine {
     DevBuf marks_buf;
     int marks_used = 0;
     std::vector<std::unique_ptr<DevBuf>> sgrad_tap;   // S = sym(D) F of every style tap
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_tune0 = nullptr, ev_tune1 = nullptr;
+    // start / stop of the last few tile calls (a ring: stx_last_tile_ms reports the newest call
+    // that has finished, so a host that runs ahead does not wait for the call it just queued)
+    static constexpr int kTimed = 4;
+    hipEvent_t ev_start[kTimed] = {}, ev_stop[kTimed] = {};
+    int ev_cur = 0;
+    hipEvent_t ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
     double flop_algorithmic = 0, flop_issued = 0;   // matrix work of the current / last tile call
     std::vector<Layer> layers;
@@ -148,17 +153,33 @@ struct stx_engine {
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
     DevBuf gram_partials, gram, dsym, dsym_pieces, symm_partials, upload;
-    DevBuf scalars;                    // device floats
-    float *scalars_host = nullptr;     // pinned mirror
-    size_t scalars_cap = 0, scalars_used = 0;
+    // Loss scalars of the calls queued so far: device floats (tile terms) and doubles (image-op
+    // reductions), each with a pinned host mirror, and the losses that will be published from
+    // them.  TWO arenas: stx_fence closes the current one behind an event and opens the other, so
+    // that a step loop can queue iteration i + 1 before it waits (stx_fence_wait) for the
+    // scalars of iteration i -- the host runs one iteration ahead of the GPU instead of letting
+    // it idle while the statistics of a step travel home.
+    struct ScalarArena {
+        DevBuf scalars;                    // device floats
+        float *host = nullptr;             // pinned mirror
+        size_t used = 0;
+        DevBuf dscalars;                   // device doubles (image-op reductions)
+        double *dhost = nullptr;
+        size_t dused = 0;
+        std::vector<PendingLoss> pending;
+        hipEvent_t fence = nullptr;
+        unsigned long long ticket = 0;     // 0: open; else closed by stx_fence and not yet published
+    };
+    ScalarArena arena[2];
+    int cur = 0;
+    unsigned long long next_ticket = 1;
+    ScalarArena &A() { return arena[cur]; }
+    size_t scalars_cap = 0;
     size_t n_tile_evals = 0;               // stx_sc_grad_tile calls (STX_Q_TILE_EVALS)
     std::vector<hipEvent_t> fence_events;     // stx_engine_wait: ring of events recorded on this stream
     size_t fence_next = 0;
-    DevBuf dscalars;                   // device doubles (image-op reductions)
-    double *dscalars_host = nullptr;
-    size_t dscalars_cap = 64, dscalars_used = 0;
+    size_t dscalars_cap = 64;
     DevBuf red_scratch;                // float partials for image-op reductions
-    std::vector<PendingLoss> pending;
 
     bool winograd = true;   // 1-D Winograd F(2,3) for the 3x3 layers (STX_WINOGRAD=0: direct only)
     bool autotune = true;   // tile-config autotuning (process-wide cache, see choose_conv_config)
@@ -224,23 +245,25 @@ double conv_flops(int K, int M, int H, int W, int ks) {
 
 
 int alloc_scalars(stx_engine *e, size_t n, size_t *index) {
-    if (e->scalars_used + n > e->scalars_cap) {
-        set_error("scalar arena exhausted (%zu + %zu > %zu)", e->scalars_used, n, e->scalars_cap);
+    stx_engine::ScalarArena &a = e->A();
+    if (a.used + n > e->scalars_cap) {
+        set_error("scalar arena exhausted (%zu + %zu > %zu)", a.used, n, e->scalars_cap);
         return STX_ERR_NOMEM;
     }
-    *index = e->scalars_used;
-    e->scalars_used += n;
+    *index = a.used;
+    a.used += n;
     return STX_OK;
 }
 
 int alloc_dscalars(stx_engine *e, size_t n, size_t *index) {
-    if (e->dscalars_used + n > e->dscalars_cap - 4) {   // the last slots serve synchronous results
-        // no wrap: results are consumed at every stx_sync, which also resets the arena
+    stx_engine::ScalarArena &a = e->A();
+    if (a.dused + n > e->dscalars_cap - 4) {   // the last slots serve synchronous results
+        // no wrap: results are consumed at every stx_sync / stx_fence_wait, which also resets the arena
         set_error("double-scalar arena exhausted; call stx_sync more often");
         return STX_ERR_NOMEM;
     }
-    *index = e->dscalars_used;
-    e->dscalars_used += n;
+    *index = a.dused;
+    a.dused += n;
     return STX_OK;
 }
 
@@ -690,33 +713,38 @@ int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int
 }
 
 int begin_timing(stx_engine *e) {
-    STX_HIP(hipEventRecord(e->ev_start, e->stream));
+    e->ev_cur = (e->ev_cur + 1) % stx_engine::kTimed;
+    STX_HIP(hipEventRecord(e->ev_start[e->ev_cur], e->stream));
     e->flop_algorithmic = e->flop_issued = 0;
     return STX_OK;
 }
 
 int end_timing(stx_engine *e) {
-    STX_HIP(hipEventRecord(e->ev_stop, e->stream));
+    STX_HIP(hipEventRecord(e->ev_stop[e->ev_cur], e->stream));
     e->timed = true;
     return STX_OK;
 }
 
-int publish_pending(stx_engine *e) {
-    for (const PendingLoss &pl : e->pending) {
+// Publishes the losses of one arena from its host mirrors (the copies have landed) and empties it.
+void publish_arena(stx_engine::ScalarArena &a) {
+    for (const PendingLoss &pl : a.pending) {
         double v = 0.0;
-        for (const LossTerm &t : pl.terms) v += t.coef * (double)e->scalars_host[t.scalar_index];
-        for (const LossTerm &t : pl.dterms) v += t.coef * e->dscalars_host[t.scalar_index];
+        for (const LossTerm &t : pl.terms) v += t.coef * (double)a.host[t.scalar_index];
+        for (const LossTerm &t : pl.dterms) v += t.coef * a.dhost[t.scalar_index];
         if (pl.out) *pl.out = v;
     }
-    e->pending.clear();
-    e->scalars_used = 0;
-    e->dscalars_used = 0;
-    return STX_OK;
+    a.pending.clear();
+    a.used = 0;
+    a.dused = 0;
+    a.ticket = 0;
 }
 
 int do_sync(stx_engine *e) {
     STX_HIP(hipStreamSynchronize(e->stream));
-    return publish_pending(e);
+    // the closed arena (if any) is the older one
+    publish_arena(e->arena[e->cur ^ 1]);
+    publish_arena(e->arena[e->cur]);
+    return STX_OK;
 }
 
 // Waits for the streams of every engine that shares e's state (weights or targets are about to be
@@ -910,20 +938,25 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
     }
     enable_peer_access(device);
     STX_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    STX_HIP(hipEventCreate(&e->ev_start));
-    STX_HIP(hipEventCreate(&e->ev_stop));
+    for (int i = 0; i < stx_engine::kTimed; ++i) {
+        STX_HIP(hipEventCreate(&e->ev_start[i]));
+        STX_HIP(hipEventCreate(&e->ev_stop[i]));
+    }
     STX_HIP(hipEventCreate(&e->ev_tune0));
     STX_HIP(hipEventCreate(&e->ev_tune1));
     if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
     if (const char *env = getenv("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
     if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
     e->scalars_cap = kScalarFloats;
-    STX_TRY(e->scalars.ensure(e->scalars_cap * sizeof(float)));
-    STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->scalars_host),
-                          e->scalars_cap * sizeof(float), hipHostMallocDefault));
-    STX_TRY(e->dscalars.ensure(e->dscalars_cap * sizeof(double)));
-    STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->dscalars_host),
-                          e->dscalars_cap * sizeof(double), hipHostMallocDefault));
+    for (stx_engine::ScalarArena &a : e->arena) {
+        STX_TRY(a.scalars.ensure(e->scalars_cap * sizeof(float)));
+        STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&a.host), e->scalars_cap * sizeof(float),
+                              hipHostMallocDefault));
+        STX_TRY(a.dscalars.ensure(e->dscalars_cap * sizeof(double)));
+        STX_HIP(hipHostMalloc(reinterpret_cast<void **>(&a.dhost), e->dscalars_cap * sizeof(double),
+                              hipHostMallocDefault));
+        STX_HIP(hipEventCreateWithFlags(&a.fence, hipEventDisableTiming));
+    }
     STX_TRY(e->red_scratch.ensure(4 * 1024 * sizeof(float)));
     {
         std::lock_guard<std::mutex> lock(e->sh->mutex);
@@ -995,17 +1028,24 @@ void stx_engine_destroy(stx_engine *e) {
         for (auto &s : e->sh->styles) s.gram->release();
     }
     DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->dsym_pieces, &e->symm_partials,
-                      &e->upload, &e->scalars, &e->dscalars, &e->red_scratch};
+                      &e->upload, &e->red_scratch};
     for (DevBuf *b : bufs) b->release();
-    if (e->scalars_host) (void)hipHostFree(e->scalars_host);
-    if (e->dscalars_host) (void)hipHostFree(e->dscalars_host);
+    for (stx_engine::ScalarArena &a : e->arena) {
+        a.scalars.release();
+        a.dscalars.release();
+        if (a.host) (void)hipHostFree(a.host);
+        if (a.dhost) (void)hipHostFree(a.dhost);
+        if (a.fence) (void)hipEventDestroy(a.fence);
+    }
     for (auto &pe : e->prof) {
         (void)hipEventDestroy(pe.start);
         (void)hipEventDestroy(pe.stop);
     }
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
-    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
-    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    for (int i = 0; i < stx_engine::kTimed; ++i) {
+        if (e->ev_start[i]) (void)hipEventDestroy(e->ev_start[i]);
+        if (e->ev_stop[i]) (void)hipEventDestroy(e->ev_stop[i]);
+    }
     if (e->ev_tune0) (void)hipEventDestroy(e->ev_tune0);
     if (e->ev_tune1) (void)hipEventDestroy(e->ev_tune1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1046,6 +1086,34 @@ int stx_sync(stx_engine *e) {
     if (!e) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     return do_sync(e);
+}
+
+int stx_fence(stx_engine *e, unsigned long long *ticket) {
+    if (!e || !ticket) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    stx_engine::ScalarArena &a = e->A();
+    STX_HIP(hipEventRecord(a.fence, e->stream));
+    a.ticket = e->next_ticket++;
+    *ticket = a.ticket;
+    e->cur ^= 1;
+    stx_engine::ScalarArena &b = e->A();
+    if (b.ticket) {      // nobody waited for the arena that is about to be reused: publish it now
+        STX_HIP(hipEventSynchronize(b.fence));
+        publish_arena(b);
+    }
+    return STX_OK;
+}
+
+int stx_fence_wait(stx_engine *e, unsigned long long ticket) {
+    if (!e) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    for (stx_engine::ScalarArena &a : e->arena) {
+        if (a.ticket && a.ticket == ticket) {
+            STX_HIP(hipEventSynchronize(a.fence));
+            publish_arena(a);
+        }
+    }
+    return STX_OK;      // (an older ticket: published long ago)
 }
 
 int stx_engine_device(stx_engine *e, int *device) {
@@ -1378,7 +1446,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 }
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-                float *sums = e->scalars.f() + si;
+                float *sums = e->A().scalars.f() + si;
                 {
                     ProfScope scope(e, "content " + b.name, 0.0, e->stream);
                     STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
@@ -1412,7 +1480,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 float *sgrad = e->sgrad_tap[k]->f() + (size_t)slot++ * b.count();
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
-                float *sc = e->scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
+                float *sc = e->A().scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
                 STX_TRY(launch_style_terms(e, e->stream, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
                                            b.name));
                 (void)HW;
@@ -1430,7 +1498,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             win.fw = win.cw = b.w;
             size_t si;
             STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-            float *sums = e->scalars.f() + si;
+            float *sums = e->A().scalars.f() + si;
             {
                 ProfScope scope(e, "dream " + b.name, 0.0, e->stream);
                 STX_TRY(content_sums_launch(e->stream, b.data.f(), nullptr, win, sums));
@@ -1537,7 +1605,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     STX_TRY(clock_mark(e));
     STX_TRY(end_timing(e));
     // mirror the scalars used so far (small) for the loss
-    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
+    STX_HIP(hipMemcpyAsync(e->A().host, e->A().scalars.ptr, e->A().used * sizeof(float),
                            hipMemcpyDeviceToHost, e->stream));
     return STX_OK;
 }
@@ -1548,7 +1616,7 @@ int sc_grad_eager(stx_engine *e, const TileCall &c, double *loss_out) {
     {
         const size_t per_call = (size_t)c.n_taps * 2100 *
                                 (size_t)std::max(1, e->sh->n_contents + e->sh->n_styles);
-        if (e->scalars_used + per_call > e->scalars_cap) STX_TRY(do_sync(e));
+        if (e->A().used + per_call > e->scalars_cap) STX_TRY(do_sync(e));
         if (per_call > e->scalars_cap) {
             set_error("stx_sc_grad_tile: %d taps need more scalar space than the arena holds", c.n_taps);
             return STX_ERR_NOMEM;
@@ -1564,7 +1632,7 @@ int sc_grad_eager(stx_engine *e, const TileCall &c, double *loss_out) {
     STX_TRY(sc_grad_run(e, c, plan, pl));
     if (c.grad_out != in.diff.ptr)
         STX_TRY(copy_out(e, c.grad_out, c.grad_mem, in.diff.ptr, in.count() * sizeof(float)));
-    e->pending.push_back(std::move(pl));
+    e->A().pending.push_back(std::move(pl));
     ++e->n_tile_evals;
     return STX_OK;
 }
@@ -1699,20 +1767,20 @@ int stx_image_regularizers(stx_engine *e, const float *img, float *grad, int H, 
     STX_TRY(e->set_device());
     size_t di;
     STX_TRY(alloc_dscalars(e, 3, &di));
-    double *terms = static_cast<double *>(e->dscalars.ptr) + di;
+    double *terms = static_cast<double *>(e->A().dscalars.ptr) + di;
     STX_TRY(regularizers_launch(e->stream, img, grad, H, W, mean_bgr, (float)tv_scale,
                                 (float)tv_power, (float)p_scale, (float)p_power, aux,
                                 (float)aux_scale, aux_roll_xy ? aux_roll_xy[0] : 0,
                                 aux_roll_xy ? aux_roll_xy[1] : 0, terms, e->red_scratch.f(),
                                 e->red_scratch.bytes / sizeof(float)));
-    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, terms, 3 * sizeof(double), hipMemcpyDeviceToHost,
+    STX_HIP(hipMemcpyAsync(e->A().dhost + di, terms, 3 * sizeof(double), hipMemcpyDeviceToHost,
                            e->stream));
     PendingLoss pl;
     pl.out = loss_out;
     pl.dterms.push_back(LossTerm{di + 0, tv_scale});
     pl.dterms.push_back(LossTerm{di + 1, p_scale});
     pl.dterms.push_back(LossTerm{di + 2, aux ? aux_scale * 0.5 : 0.0});
-    e->pending.push_back(std::move(pl));
+    e->A().pending.push_back(std::move(pl));
     return STX_OK;
 }
 
@@ -1722,16 +1790,16 @@ int stx_image_swt_haar(stx_engine *e, const float *img, float *grad, int H, int 
     STX_TRY(e->set_device());
     size_t di;
     STX_TRY(alloc_dscalars(e, 1, &di));
-    double *term = static_cast<double *>(e->dscalars.ptr) + di;
+    double *term = static_cast<double *>(e->A().dscalars.ptr) + di;
     STX_TRY(swt_haar_launch(e->stream, img, grad, H, W, roll_xy ? roll_xy[0] : 0,
                             roll_xy ? roll_xy[1] : 0, (float)scale, (float)power, term,
                             e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
-    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, term, sizeof(double), hipMemcpyDeviceToHost,
+    STX_HIP(hipMemcpyAsync(e->A().dhost + di, term, sizeof(double), hipMemcpyDeviceToHost,
                            e->stream));
     PendingLoss pl;
     pl.out = loss_out;
     pl.dterms.push_back(LossTerm{di, scale});
-    e->pending.push_back(std::move(pl));
+    e->A().pending.push_back(std::move(pl));
     return STX_OK;
 }
 
@@ -1745,10 +1813,10 @@ int stx_adam_step(stx_engine *e, float *params, const float *grad, float *g1, fl
 }
 
 static int sync_scalar(stx_engine *e, size_t di, int n, double *out) {
-    STX_HIP(hipMemcpyAsync(e->dscalars_host + di, static_cast<double *>(e->dscalars.ptr) + di,
+    STX_HIP(hipMemcpyAsync(e->A().dhost + di, static_cast<double *>(e->A().dscalars.ptr) + di,
                            n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     STX_HIP(hipStreamSynchronize(e->stream));
-    for (int i = 0; i < n; ++i) out[i] = e->dscalars_host[di + i];
+    for (int i = 0; i < n; ++i) out[i] = e->A().dhost[di + i];
     return STX_OK;
 }
 
@@ -1756,7 +1824,7 @@ int stx_vec_dot(stx_engine *e, const float *x, const float *y, size_t n, double 
     if (!e || !x || !y || !out) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     const size_t di = e->dscalars_cap - 2;   // reserved slot for synchronous scalar results
-    STX_TRY(dot_launch(e->stream, x, y, n, static_cast<double *>(e->dscalars.ptr) + di,
+    STX_TRY(dot_launch(e->stream, x, y, n, static_cast<double *>(e->A().dscalars.ptr) + di,
                        e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
     return sync_scalar(e, di, 1, out);
 }
@@ -1765,7 +1833,7 @@ int stx_vec_mean_abs(stx_engine *e, const float *x, size_t n, double *out) {
     if (!e || !x || !out || !n) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     const size_t di = e->dscalars_cap - 2;
-    STX_TRY(abs_sum_launch(e->stream, x, n, static_cast<double *>(e->dscalars.ptr) + di,
+    STX_TRY(abs_sum_launch(e->stream, x, n, static_cast<double *>(e->A().dscalars.ptr) + di,
                            e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
     STX_TRY(sync_scalar(e, di, 1, out));
     *out /= (double)n;
@@ -1816,13 +1884,32 @@ int stx_image_step_stats(stx_engine *e, const float *avg, float *old, int H, int
     if (!e || !avg || !old || !stats || H <= 0 || W <= 0) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     const size_t di = e->dscalars_cap - 2;
-    STX_TRY(step_stats_launch(e->stream, avg, old, H, W, static_cast<double *>(e->dscalars.ptr) + di,
+    STX_TRY(step_stats_launch(e->stream, avg, old, H, W, static_cast<double *>(e->A().dscalars.ptr) + di,
                               e->red_scratch.f(), e->red_scratch.bytes / sizeof(float)));
     double raw[2];
     STX_TRY(sync_scalar(e, di, 2, raw));
     const double n = 3.0 * H * W;
     stats[0] = raw[0] / n;
     stats[1] = std::sqrt(raw[1] / n);
+    return STX_OK;
+}
+
+int stx_image_step_stats_async(stx_engine *e, const float *avg, float *old, int H, int W,
+                               double raw_sums[2]) {
+    if (!e || !avg || !old || !raw_sums || H <= 0 || W <= 0) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    size_t di;
+    STX_TRY(alloc_dscalars(e, 2, &di));
+    double *dev = static_cast<double *>(e->A().dscalars.ptr) + di;
+    STX_TRY(step_stats_launch(e->stream, avg, old, H, W, dev, e->red_scratch.f(),
+                              e->red_scratch.bytes / sizeof(float)));
+    STX_HIP(hipMemcpyAsync(e->A().dhost + di, dev, 2 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    for (int i = 0; i < 2; ++i) {
+        PendingLoss pl;
+        pl.out = raw_sums + i;
+        pl.dterms.push_back(LossTerm{di + (size_t)i, 1.0});
+        e->A().pending.push_back(std::move(pl));
+    }
     return STX_OK;
 }
 
@@ -1932,16 +2019,16 @@ int stx_op_style_terms(stx_engine *e, const float *feat, int C, int h, int w,
     STX_TRY(do_sync(e));
     size_t si;
     STX_TRY(alloc_scalars(e, 2, &si));
-    float *sc = e->scalars.f() + si;
+    float *sc = e->A().scalars.f() + si;
     STX_TRY(launch_style_terms(e, e->stream, feat, C, h, w, gram_target, sgrad, sc, "op"));
     if (normalized_out)
         STX_TRY(inject_style_launch(e->stream, normalized_out, sgrad, count, sc + 1, 1.0f, false));
-    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, e->scalars_used * sizeof(float),
+    STX_HIP(hipMemcpyAsync(e->A().host, e->A().scalars.ptr, e->A().used * sizeof(float),
                            hipMemcpyDeviceToHost, e->stream));
     STX_HIP(hipStreamSynchronize(e->stream));
-    if (half_sumsq) *half_sumsq = 0.5 * (double)e->scalars_host[si];
-    if (abs_sum) *abs_sum = (double)e->scalars_host[si + 1];
-    e->scalars_used = 0;
+    if (half_sumsq) *half_sumsq = 0.5 * (double)e->A().host[si];
+    if (abs_sum) *abs_sum = (double)e->A().host[si + 1];
+    e->A().used = 0;
     return STX_OK;
 }
 
@@ -1967,18 +2054,18 @@ int stx_op_content_terms(stx_engine *e, const float *feat, int C, int h, int w,
     STX_TRY(do_sync(e));
     size_t si;
     STX_TRY(alloc_scalars(e, 2 + 2 * 1024, &si));
-    float *s = e->scalars.f() + si;
+    float *s = e->A().scalars.f() + si;
     STX_TRY(content_sums_launch(e->stream, feat, content, win, s));
     if (normalized_out)
         STX_TRY(inject_content_launch(e->stream, normalized_out, feat, content, win, s, 1.0f, false));
-    STX_HIP(hipMemcpyAsync(e->scalars_host, e->scalars.ptr, (si + 2) * sizeof(float),
+    STX_HIP(hipMemcpyAsync(e->A().host, e->A().scalars.ptr, (si + 2) * sizeof(float),
                            hipMemcpyDeviceToHost, e->stream));
     STX_HIP(hipStreamSynchronize(e->stream));
     if (sums) {
-        sums[0] = (double)e->scalars_host[si];
-        sums[1] = (double)e->scalars_host[si + 1];
+        sums[0] = (double)e->A().host[si];
+        sums[1] = (double)e->A().host[si + 1];
     }
-    e->scalars_used = 0;
+    e->A().used = 0;
     return STX_OK;
 }
 
@@ -2026,8 +2113,19 @@ int stx_last_tile_ms(stx_engine *e, float *ms) {
         return STX_ERR_STATE;
     }
     STX_TRY(e->set_device());
-    STX_HIP(hipEventSynchronize(e->ev_stop));
-    STX_HIP(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    // the newest call that has finished; if none of the last few has, wait for the newest
+    int pick = e->ev_cur;
+    for (int k = 0; k < stx_engine::kTimed; ++k) {
+        const int i = (e->ev_cur - k + stx_engine::kTimed) % stx_engine::kTimed;
+        const hipError_t q = hipEventQuery(e->ev_stop[i]);
+        if (q == hipSuccess) {
+            pick = i;
+            break;
+        }
+        (void)hipGetLastError();      // hipErrorNotReady (or an event never recorded)
+    }
+    STX_HIP(hipEventSynchronize(e->ev_stop[pick]));
+    STX_HIP(hipEventElapsedTime(ms, e->ev_start[pick], e->ev_stop[pick]));
     return STX_OK;
 }
 

@@ -195,6 +195,18 @@ class TileEngine:
             del self._results[:2048]
         return result
 
+    def fence(self):
+        """Closes the pending values queued so far behind an event and returns a ticket for
+        ``wait_fence`` (stx_fence): the host can queue the next iteration first and collect this
+        one's losses afterwards, without waiting for the newer work."""
+        ticket = ctypes.c_ulonglong(0)
+        lib.call('stx_fence', self.handle, ctypes.byref(ticket))
+        return ticket.value
+
+    def wait_fence(self, ticket):
+        """Waits for the fence's event only and publishes the values it closed."""
+        lib.call('stx_fence_wait', self.handle, int(ticket))
+
     def wait_for(self, other):
         """Orders this engine's stream behind what ``other`` has queued so far (no host wait)."""
         if other is not self:

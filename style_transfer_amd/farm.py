@@ -44,7 +44,7 @@ class LazyLoss:
     work -- one host synchronisation per optimizer step instead of one per term."""
 
     def __init__(self):
-        self.parts, self.engines, self._value = [], [], None
+        self.parts, self.engines, self._value, self._tickets = [], [], None, None
 
     def add(self, part, engine):
         """part: anything with a ``loss`` or ``value`` attribute that is valid after
@@ -55,12 +55,28 @@ class LazyLoss:
             self.engines.append(engine)
         return self
 
+    def seal(self, also=()):
+        """Closes the loss behind a fence on every engine that contributes (stx_fence), and on
+        the engines in ``also`` (whose other pending values -- step statistics -- are published
+        with it): ``float(loss)`` then waits for exactly these terms and not for whatever the
+        host has queued since -- the step loop can run one iteration ahead of the GPU."""
+        assert self._value is None and self._tickets is None
+        for eng in also:
+            if eng not in self.engines:
+                self.engines.append(eng)
+        self._tickets = [(eng, eng.fence()) for eng in self.engines]
+        return self
+
     def __float__(self):
         if self._value is None:
-            for eng in self.engines:
-                eng.sync()
+            if self._tickets is not None:
+                for eng, ticket in self._tickets:
+                    eng.wait_fence(ticket)
+            else:
+                for eng in self.engines:
+                    eng.sync()
             self._value = float(sum(p.loss if hasattr(p, 'loss') else p.value for p in self.parts))
-            self.parts, self.engines = [], []
+            self.parts, self.engines, self._tickets = [], [], None
         return self._value
 
 

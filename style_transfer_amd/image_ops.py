@@ -141,6 +141,26 @@ def step_stats(engine, avg, old):
     return out[0], out[1]
 
 
+class PendingStats:
+    """step_stats whose two sums are still on their way: ``values()`` after the engine's pending
+    values were published (sync, or wait_fence on a later fence)."""
+
+    def __init__(self, n):
+        self._raw = (ctypes.c_double * 2)(float('nan'), float('nan'))
+        self._n = n
+
+    def values(self):
+        return self._raw[0] / self._n, float(np.sqrt(self._raw[1] / self._n))
+
+
+def step_stats_async(engine, avg, old):
+    """step_stats without the host wait (stx_image_step_stats_async); old <- avg in stream order."""
+    _, H, W = avg.shape
+    out = engine.keep_until_sync(PendingStats(3.0 * H * W))
+    lib.call('stx_image_step_stats_async', engine.handle, avg.ptr, old.ptr, H, W, out._raw)
+    return out
+
+
 def to_u8(engine, img, mean_bgr):
     """RGB HWC uint8 ndarray of img + mean, clipped and truncated like the reference."""
     _, H, W = img.shape

@@ -65,6 +65,8 @@ SIGNATURES = {
     'stx_engine_query': [_vp, _i, c_double_p],
     'stx_set_conv_weights': [_vp, ctypes.c_char_p, _vp, _vp, _i],
     'stx_sync': [_vp],
+    'stx_fence': [_vp, ctypes.POINTER(ctypes.c_ulonglong)],
+    'stx_fence_wait': [_vp, ctypes.c_ulonglong],
     'stx_engine_device': [_vp, c_int_p],
     'stx_engine_stream': [_vp, ctypes.POINTER(_vp)],
     'stx_malloc': [_vp, _sz, ctypes.POINTER(_vp)],
@@ -98,6 +100,7 @@ SIGNATURES = {
     'stx_vec_axpy_dev': [_vp, _d, _vp, _d, _d, _vp, _d, _vp, _vp, _sz],
     'stx_vec_scale_dev': [_vp, _d, _vp, _d, _vp, _sz],
     'stx_image_step_stats': [_vp, _vp, _vp, _i, _i, c_double_p],
+    'stx_image_step_stats_async': [_vp, _vp, _vp, _i, _i, c_double_p],
     'stx_image_to_u8': [_vp, _vp, _i, _i, c_float_p, _vp],
     'stx_op_conv_forward': [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp],
     'stx_op_conv_backward_data': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],

@@ -142,6 +142,7 @@ class StyleTransfer:
         self.current_raw = None     # DeviceArray: averaged iterate of the last step
         self.step = 0
         self.step_times = []
+        self.steps_queued = 0       # iterations queued so far in this run (all scales)
         self._converted = {}        # id(PIL image) -> (image, float array), filled by the helper thread
         # --swt-weight (style_transfer.py:716-720) calls PyWavelets, which is not part of the
         # reference tree; its transform is restated for the command line's defaults only
@@ -293,6 +294,30 @@ class StyleTransfer:
         jitter_scale, _ = self.farm.layer_info(deepest_content)
         img_size = np.array(self.img.shape[-2:])
 
+        # The host runs ONE iteration ahead of the GPU where it can: iteration i + 1 is queued
+        # before the loss and statistics of iteration i are collected (a fence per iteration,
+        # LazyLoss.seal), so the GPU does not idle while those travel home and the host queues
+        # the next ~350 launches.  The reference blocks on every iteration (style_transfer.py:
+        # 799-815); the values and their order are the same.  Not with L-BFGS (its curvature test
+        # needs a dot product on the host inside the step), not with --jitter (targets change
+        # every iteration), not with a callback this loop knows nothing about (it may read the
+        # image of the step it is called for: only callbacks with ``wants_image`` are run behind).
+        run_ahead = (args.optimizer == 'adam' and not jitter and
+                     (callback is None or hasattr(callback, 'wants_image')))
+        in_flight = []
+        t_prev = [time.perf_counter()]
+
+        def finish(item):
+            step_i, loss_i, stats_i = item
+            loss_v = float(loss_i)          # waits for that iteration's fences only
+            update_size, tv_loss = stats_i.values()
+            now = time.perf_counter()
+            self.step_times.append(now - t_prev[0])
+            t_prev[0] = now
+            if callback is not None:
+                callback(step=step_i, update_size=update_size, loss=loss_v, tv_loss=tv_loss,
+                         transfer=self)
+
         for step in range(1, iterations + 1):
             t0 = time.perf_counter()
             state.step = step - 1
@@ -314,6 +339,20 @@ class StyleTransfer:
                        dd_layers, dd_weight, content_roll)
             avg_img, loss = self.optimizer.update(lambda p: self.eval_loss_and_grad(p, sc_args))
             self.optimizer.roll(-roll)
+            self.steps_queued += 1
+            if run_ahead:
+                stats = image_ops.step_stats_async(self.engine, avg_img, self.old_avg)
+                loss.seal(also=[self.engine])
+                self.current_raw = avg_img
+                if in_flight:
+                    finish(in_flight.pop())
+                in_flight.append((step, loss, stats))
+                # a callback that will look at this step's image gets it before the next step
+                # overwrites it
+                if step == iterations or (callback is not None and
+                                          callback.wants_image(self.steps_queued)):
+                    finish(in_flight.pop())
+                continue
             update_size, tv_loss = image_ops.step_stats(self.engine, avg_img, self.old_avg)
             loss = float(loss)              # (everything is finished by now: publishes the terms)
             self.current_raw = avg_img

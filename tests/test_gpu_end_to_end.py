@@ -18,7 +18,26 @@ from style_transfer_amd.weights import synthetic_weights
 pytestmark = pytest.mark.gpu
 
 
-def test_transfer_multiscale_matches_reference_run(golden):
+class _BehindCallback:
+    """A callback the step loop may serve one iteration late (it declares which iterations' images
+    it reads: the second one here, which therefore is collected before the third is queued)."""
+
+    def __init__(self, log):
+        self.log, self.asked = log, []
+
+    def wants_image(self, n):
+        self.asked.append(n)
+        return n == 2
+
+    def __call__(self, **kw):
+        self.log.append((kw['step'], kw['update_size'], kw['loss'], kw['tv_loss']))
+
+
+@pytest.mark.parametrize('run_ahead', [False, True])
+def test_transfer_multiscale_matches_reference_run(golden, run_ahead):
+    """run_ahead: the host queues iteration i + 1 before it collects iteration i (a callback with
+    ``wants_image``: the command line's Progress) -- same values, same order as the reference's
+    blocking loop."""
     from argparse import Namespace
     argv = str(golden['e2e.argv']).split()
     state = Namespace()
@@ -28,10 +47,12 @@ def test_transfer_multiscale_matches_reference_run(golden):
     st = StyleTransfer(farm, args, state)
     log = []
     np.random.seed(args.seed)
+    behind = _BehindCallback(log)
     st.transfer_multiscale([Image.fromarray(golden['e2e.content_u8'])],
                            [Image.fromarray(golden['e2e.style_u8'])],
-                           callback=lambda **kw: log.append(
+                           callback=behind if run_ahead else lambda **kw: log.append(
                                (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+    assert behind.asked == ([1, 2, 4] if run_ahead else [])      # (the last iteration of a scale is always collected)
     ref = golden['e2e.log']
     got = np.float64(log)
     assert got.shape == ref.shape
