@@ -221,18 +221,14 @@ class TileFarm:
                 self._roll_host(f, -xy * 32 // self.layer_info(layer)[0])
         return feats
 
-    def prepare_features_device(self, img, layers, tile_size=512, passes=10, roll=None, rng=None,
-                                log=print):
+    def prepare_features_device(self, img, layers, tile_size=512, passes=10, roll=None):
         """prepare_features with everything on the master GPU: the image is uploaded once, tiles
         are cut with the roll as an index offset, tile maps are stitched by stx_map_place and a
         pass is folded into the average by stx_map_roll_add (acc += roll(feats, -shift) / passes,
         which is the reference's roll-accumulate-unroll of the accumulator, bit for bit).
         Returns {layer: DeviceArray}.  Same RNG draws as the reference.  ``roll``: the maps of
         roll2(img, roll) instead (preprocess_images(..., roll=xy) of the reference's --jitter
-        mode, style_transfer.py:789-794); the result stays in that rolled frame.  ``rng``: the
-        generator the tilings' shifts are drawn from (default: the global numpy RNG, like the
-        reference); ``log``: where the progress line goes."""
-        rng = np.random if rng is None else rng
+        mode, style_transfer.py:789-794); the result stays in that rolled frame."""
         eng = self.master
         img = np.ascontiguousarray(img, np.float32)
         hw = np.array(img.shape[-2:])
@@ -242,9 +238,9 @@ class TileFarm:
         rects = tile_grid(hw, tile_size)
         if len(rects) > 1 and self.verbose:
             nx = (hw[1] - 1) // tile_size + 1
-            log('Using %dx%d tiles of size %dx%d (x %d passes).' %
-                (nx, len(rects) // nx, rects[0][3] - rects[0][2], rects[0][1] - rects[0][0],
-                 passes))
+            print('Using %dx%d tiles of size %dx%d (x %d passes).' %
+                  (nx, len(rects) // nx, rects[0][3] - rects[0][2], rects[0][1] - rects[0][0],
+                   passes))
         full, acc = {}, {}
         for layer in layers:
             scale, ch = self.layer_info(layer)
@@ -255,7 +251,7 @@ class TileFarm:
         for i in range(passes):
             xy = np.array((0, 0))
             if i > 0:
-                xy = np.int32(rng.uniform(size=2) * hw) // 32
+                xy = np.int32(np.random.uniform(size=2) * hw) // 32
             shift = xy * 32
             cut_shift = shift if roll is None else shift + np.asarray(roll, np.int64)
             for rect in rects:

@@ -16,7 +16,6 @@ from argparse import Namespace
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 import json
-import os
 import time
 
 import numpy as np
@@ -145,12 +144,6 @@ class StyleTransfer:
         self.step_times = []
         self.steps_queued = 0       # iterations queued so far in this run (all scales)
         self._converted = {}        # id(PIL image) -> (image, float array), filled by the helper thread
-        # the targets of the NEXT pyramid level, computed on a second engine of the master GPU while
-        # this level steps (transfer_multiscale / _prefetch_targets)
-        self._prep_farm = None
-        self._next_level = None     # Future -> (content pictures, style pictures, converted) of the next level
-        self._prefetched = None     # Future -> (contents, styles, messages, RNG state after)
-        self._pool = None
         # --swt-weight (style_transfer.py:716-720) calls PyWavelets, which is not part of the
         # reference tree; its transform is restated for the command line's defaults only
         raw = getattr(getattr(args, 'ns', args), 'swt_weight', 0)
@@ -186,7 +179,7 @@ class StyleTransfer:
         return self.get_image() if self.current_raw is not None else None
 
     # -------------------------------------------------------------------------- preprocessing
-    def _style_variants(self, index, image, say=print):
+    def _style_variants(self, index, image):
         """The resamplings of one style image that contribute a Gram each: smallest ladder size
         first, stopping after the first one that no longer shrinks the picture; variants under
         32 pixels are skipped (style_transfer.py:505-531)."""
@@ -197,7 +190,7 @@ class StyleTransfer:
             scaled = resize_to_fit(image, size, div=self.args.div)
             last = max(scaled.size) == max(image.size)
             if min(scaled.size) >= 32:
-                say('Processing style {} at {}x{}.'.format(index + 1, *scaled.size))
+                print('Processing style {} at {}x{}.'.format(index + 1, *scaled.size))
                 yield scaled
             if last:
                 return
@@ -208,76 +201,27 @@ class StyleTransfer:
         image and ladder size, and the tiling-averaged content features
         (style_transfer.py:488-554).  Everything stays on the master GPU.  ``roll`` (--jitter,
         once per iteration): features of the pictures rolled by it, one pass, no messages."""
-        contents, styles = self._compute_targets(self.farm, content_images, style_images,
-                                                 content_layers, style_layers, not self.styles,
-                                                 roll=roll, log=print if roll is None else None)
-        self.styles += styles
-        self.contents += contents
-
-    def _compute_targets(self, farm, content_images, style_images, content_layers, style_layers,
-                         want_styles, roll=None, rng=None, log=print):
-        """(contents, styles) of one scale on ``farm`` (the run's farm, or the one-engine farm the
-        next level's targets are prefetched on).  ``log``: where the reference's progress lines
-        go (None: nowhere); ``rng``: the generator the tiling shifts come from."""
-        tile = self.args.tile_size
-        say = log if log is not None else (lambda line: None)
-        say('Preprocessing the style image(s)...')
-        styles = []
-        if want_styles:
+        farm, tile = self.farm, self.args.tile_size
+        if roll is None:
+            print('Preprocessing the style image(s)...')
+        if not self.styles:
             total, count = {}, 0
             for index, image in enumerate(style_images):
-                for variant in self._style_variants(index, image, say):
+                for variant in self._style_variants(index, image):
                     feats = farm.prepare_features_device(self.pil_to_image(variant), style_layers,
-                                                         tile, passes=1, roll=roll, rng=rng, log=say)
+                                                         tile, passes=1, roll=roll)
                     for layer, feat in feats.items():
                         gram = farm.gram_matrix(feat)
                         feat.free()
                         total[layer] = gram if layer not in total else total[layer] + gram
                     count += 1
-            styles.append({layer: gram / count for layer, gram in total.items()})
-        say('Preprocessing the content image(s)...')
-        contents = [farm.prepare_features_device(self.pil_to_image(image), content_layers, tile,
-                                                 passes=10 if roll is None else 1, roll=roll,
-                                                 rng=rng, log=say)
-                    for image in content_images]
-        return contents, styles
-
-    def _prefetch_targets(self, iterations, content_layers, style_layers):
-        """Starts the NEXT pyramid level's preprocessing on a second engine of the master GPU (its
-        own HIP stream and activation buffers, the master's weights and filter banks) while this
-        level steps.  The reference preprocesses a level when it gets there, drawing the shifts
-        of its ten content tilings from the global RNG after this level's iterations have drawn
-        theirs (two numbers each, style_transfer.py:777-779) -- so the draws are made from a
-        copy of the generator advanced by exactly those, and the global generator is put into
-        the state the copy ends in when the level is reached (transfer()).  Same kernels on the
-        same data in the same order: the targets are bit-identical to the in-line ones."""
-        from .engine import TileEngine
-        from .farm import TileFarm
-        if self._next_level is None or self._pool is None:
-            return
-        if self._prep_farm is None:
-            engine = TileEngine(self.farm.net, self.engine.device, share=self.engine)
-            self._prep_farm = TileFarm(self.farm.net, [self.engine.device], verbose=self.farm.verbose,
-                                       engines=[engine])
-        rng = np.random.RandomState()
-        rng.set_state(np.random.get_state())
-        for _ in range(iterations):
-            rng.uniform(-0.5, 0.5, size=2)
-        pictures = self._next_level
-        want_styles = not self.args.style_multiscale
-
-        def job():
-            # (same worker thread as the resize: it has finished; the main thread converts no
-            # pictures while it steps, so the look-up table can take the next level's entries)
-            content_images, style_images, converted = pictures.result()
-            self._converted.update(converted)
-            messages = []
-            contents, styles = self._compute_targets(self._prep_farm, content_images, style_images,
-                                                     content_layers, style_layers, want_styles,
-                                                     rng=rng, log=messages.append)
-            self._prep_farm.master.sync()
-            return contents, styles, messages, rng.get_state()
-        self._prefetched = self._pool.submit(job)
+            self.styles.append({layer: gram / count for layer, gram in total.items()})
+        if roll is None:
+            print('Preprocessing the content image(s)...')
+        self.contents += [farm.prepare_features_device(self.pil_to_image(image), content_layers,
+                                                       tile, passes=10 if roll is None else 1,
+                                                       roll=roll)
+                          for image in content_images]
 
     def _drop_contents(self):
         for content in self.contents:
@@ -332,20 +276,10 @@ class StyleTransfer:
         self._drop_contents()                  # device-resident maps of the previous scale
         if not args.style_multiscale:
             self.styles = []
-        if self._prefetched is not None:
-            # this level's targets were computed while the previous one stepped (_prefetch_targets)
-            contents, styles, messages, rng_state = self._prefetched.result()
-            self._prefetched = None
-            for line in messages:
-                print(line)
-            np.random.set_state(rng_state)
-            self.contents += contents
-            self.styles += styles
-        else:
-            # --jitter: the content maps are recomputed every iteration from the shifted picture
-            # (style_transfer.py:757-763,789-794), only the style targets are fixed per scale
-            self.preprocess_images([] if jitter else content_images, style_images,
-                                   [] if jitter else content_layers, style_layers)
+        # --jitter: the content maps are recomputed every iteration from the shifted picture
+        # (style_transfer.py:757-763,789-794), only the style targets are fixed per scale
+        self.preprocess_images([] if jitter else content_images, style_images,
+                               [] if jitter else content_layers, style_layers)
         self.farm.set_contents_and_styles(self.contents, self.styles)
 
         if self.grad is None or self.grad.shape != self.img.shape:
@@ -370,9 +304,6 @@ class StyleTransfer:
         # image of the step it is called for: only callbacks with ``wants_image`` are run behind).
         run_ahead = (args.optimizer == 'adam' and not jitter and
                      (callback is None or hasattr(callback, 'wants_image')))
-        if not jitter and os.environ.get('STX_PREFETCH_TARGETS', '1') != '0':
-            # (the global RNG is exactly where the step loop will find it: the copy is taken now)
-            self._prefetch_targets(iterations, content_layers, style_layers)
         in_flight = []
         t_prev = [time.perf_counter()]
 
@@ -477,7 +408,7 @@ class StyleTransfer:
         # The pictures of the next level are resized on a helper thread while the GPU works on
         # the current one (Pillow releases the interpreter lock inside resize; the main thread
         # sits in stx_sync most of the time): 0.1 s per 4096-pixel picture and level otherwise.
-        pool = self._pool = ThreadPoolExecutor(max_workers=1)
+        pool = ThreadPoolExecutor(max_workers=1)
         try:
             pending = pool.submit(resized, plans[0]) if plans else None
             previous = None
@@ -486,9 +417,6 @@ class StyleTransfer:
                 print('\nScale %d, image size %dx%d.\n' % (plan.index + 1, w, h))
                 contents, styles, self._converted = pending.result()
                 pending = pool.submit(resized, plans[number + 1]) if number + 1 < len(plans) else None
-                # (the same worker computes the next level's targets from these pictures once
-                # this level's step loop is about to start: _prefetch_targets)
-                self._next_level = pending
                 if aux_image:
                     if self.aux_image is not None:
                         self.aux_image.free()
@@ -503,5 +431,4 @@ class StyleTransfer:
                 previous = self.transfer(plan.iterations, contents, styles, callback)
         finally:
             pool.shutdown()
-            self._pool = None
         return self.current_output

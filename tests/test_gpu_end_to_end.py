@@ -71,37 +71,6 @@ def test_transfer_multiscale_matches_reference_run(golden, run_ahead):
     farm.close()
 
 
-def test_prefetched_targets_and_run_ahead_change_no_bit(golden, monkeypatch):
-    """The next pyramid level's targets computed on a second engine while this level steps (the
-    tiling shifts drawn from a copy of the global RNG advanced past this level's iterations), and
-    the step loop running one iteration ahead of the GPU, against the plain schedule (targets in
-    line, every iteration collected before the next is queued): the same losses, statistics and
-    final image, bit for bit, and the global RNG ends in the same state."""
-    from argparse import Namespace
-    argv = str(golden['e2e.argv']).split()
-    net = builtin_net('vgg19')
-    weights = synthetic_weights(net, 0)
-    runs = []
-    for prefetch in ('0', '1'):
-        monkeypatch.setenv('STX_PREFETCH_TARGETS', prefetch)
-        state = Namespace()
-        args = parse_args(state, argv, config_py=False)
-        farm = TileFarm(net, [0], weights, verbose=False)
-        st = StyleTransfer(farm, args, state)
-        log = []
-        np.random.seed(args.seed)
-        callback = _BehindCallback(log) if prefetch == '1' else \
-            (lambda **kw: log.append((kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
-        st.transfer_multiscale([Image.fromarray(golden['e2e.content_u8'])],
-                               [Image.fromarray(golden['e2e.style_u8'])], callback=callback)
-        assert (st._prep_farm is not None) == (prefetch == '1')
-        runs.append((log, st.current_raw.get(), np.random.get_state()[1].copy()))
-        farm.close()
-    assert runs[0][0] == runs[1][0]
-    assert np.array_equal(runs[0][1], runs[1][1])
-    assert np.array_equal(runs[0][2], runs[1][2])
-
-
 def test_device_preprocessing_equals_host_stitching():
     """prepare_features on the GPU (cut with roll offset, stx_map_place, stx_map_roll_add) must be
     bit-identical to the host-stitched version that mirrors the reference line by line."""
