@@ -71,6 +71,33 @@ def test_transfer_multiscale_matches_reference_run(golden, run_ahead):
     farm.close()
 
 
+def test_run_ahead_step_loop_changes_no_bit(golden):
+    """The step loop running one iteration ahead of the GPU (fences, asynchronous statistics)
+    against the blocking schedule (every iteration collected before the next is queued): the same
+    losses, statistics and final image, bit for bit, and the same global RNG state at the end."""
+    from argparse import Namespace
+    argv = str(golden['e2e.argv']).split()
+    net = builtin_net('vgg19')
+    weights = synthetic_weights(net, 0)
+    runs = []
+    for ahead in (False, True):
+        state = Namespace()
+        args = parse_args(state, argv, config_py=False)
+        farm = TileFarm(net, [0], weights, verbose=False)
+        st = StyleTransfer(farm, args, state)
+        log = []
+        np.random.seed(args.seed)
+        callback = _BehindCallback(log) if ahead else \
+            (lambda **kw: log.append((kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+        st.transfer_multiscale([Image.fromarray(golden['e2e.content_u8'])],
+                               [Image.fromarray(golden['e2e.style_u8'])], callback=callback)
+        runs.append((log, st.current_raw.get(), np.random.get_state()[1].copy()))
+        farm.close()
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][2], runs[1][2])
+
+
 def test_device_preprocessing_equals_host_stitching():
     """prepare_features on the GPU (cut with roll offset, stx_map_place, stx_map_roll_add) must be
     bit-identical to the host-stitched version that mirrors the reference line by line."""
