@@ -240,8 +240,8 @@ class FarmJob:
             self.step()
         self.fence()
         self.group_ms.clear()
-        # (clock_marks: the engines record the shader clock twice per tile evaluation, 20 us each --
-        # the second, longer measurement only, never the headline's timed steps)
+        # (clock_marks: one workgroup of every 2-D Winograd launch times its chunk loop with the core
+        # and the 100 MHz counters -- the second, longer measurement only, never the headline's steps)
         engines = self.farm.engines[:self.tiles_per_step] if clock_marks else []
         for e in engines:
             e.clock_marks(True)
@@ -444,11 +444,14 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
                     'six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 form and are '
                     'counted at that) over the HIP-event time of the launch group, against the fp32 '
                     'MFMA peak at 2.4 GHz; frac_driver_clock = the same work over the wall-clock '
-                    'ms_per_step; clock_mhz is the shader clock during the second, longer measurement '
-                    '(`steady`; stx_clock_marks: two 20-microsecond readings of core cycles against the '
-                    '100 MHz counter per tile evaluation, each good to about 3 %; the median), peak_at_clock '
-                    'the fp32 MFMA peak at min(that clock, 2.4 GHz) and frac_at_clock = achieved / '
-                    'peak_at_clock; '
+                    'ms_per_step; clock_mhz is the shader clock INSIDE the 2-D Winograd convolution '
+                    'kernels during the second, longer measurement (`steady`; stx_clock_marks: one '
+                    'workgroup of every launch reads core cycles and the 100 MHz counter around its '
+                    'chunk loop; the median over the launches, with the 10th / 90th percentile), '
+                    'peak_at_clock the fp32 MFMA peak at min(that clock, 2.4 GHz) and frac_at_clock = '
+                    'achieved / peak_at_clock: the part is power-limited under fp32 MFMA load and does '
+                    'not hold its 2.4 GHz there (round 3 read the clock between the heavy kernels and '
+                    'saw 2.43 GHz); '
                     'frac_round2_accounting counts Gram and SYMM in full as '
                     'round 2 did (they ran on the fp32 pipe then); achieved_direct_equiv credits '
                     'every convolution as a direct one (SURVEY 8d: 1 514 240 FLOP per tile pixel) '

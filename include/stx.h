@@ -344,8 +344,9 @@ int stx_op_content_terms(stx_engine *e, const float *feat, int channels, int h, 
 /* Per-kernel-group timing for tuning and for bench.py's roofline figures: while enabled, every
  * launch group of the tile path (one conv / pool / Gram / SYMM / injection) is bracketed by HIP
  * events on the engine stream.  stx_profile_read synchronises, writes one line per group
- * "label<TAB>milliseconds<TAB>algorithmic_flops" into buf (NUL-terminated, truncated to buf_len;
- * *needed receives the full size) and clears the record. */
+ * "label<TAB>milliseconds<TAB>algorithmic_flops<TAB>MHz" into buf (NUL-terminated, truncated to
+ * buf_len; *needed receives the full size) and clears the record.  MHz: the shader clock inside the
+ * group's convolution kernel while stx_clock_marks is on (0 otherwise / for other groups). */
 int stx_profile_enable(stx_engine *e, int on);
 int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed);
 
@@ -361,16 +362,19 @@ int stx_last_tile_ms(stx_engine *e, float *ms);
  * 4/9 of it).  Gram / SYMM products are not included. */
 int stx_last_tile_flops(stx_engine *e, double *algorithmic, double *issued);
 
-/* The shader clock the GPU sustains while it works (measurement only; nothing in the reference
- * corresponds).  While stx_clock_marks is on, every stx_sc_grad_tile of this engine queues two ONE-WAVE
- * kernels on its stream -- after the forward pass and at the end of the backward pass -- that read
- * the core-cycle counter and the constant 100 MHz counter, doze for 20 microseconds and read them
- * again: the clock at that moment, with whatever the GPU's other streams are running.  (A probe
- * that runs beside the work for its whole length would hold one of the hardware queues the streams
- * are multiplexed onto.)  stx_clock_marks_read synchronises the stream, returns the marks recorded
- * since the last read in MHz, oldest first (*n_values <= max_values; at most 8192 are kept) and
- * clears them.  bench.py switches them on for its second, longer measurement only: the fp32 MFMA
- * peak scales with this clock, which depends on the kernels AND on their operands' bits. */
+/* The shader clock the GPU sustains INSIDE its dominant kernel (measurement only; nothing in the
+ * reference corresponds).  While stx_clock_marks is on, one workgroup of every 2-D Winograd
+ * convolution launch of this engine (the kernel that does 80 % of a tile evaluation's work) reads
+ * the core-cycle counter and the constant 100 MHz counter before and after its chunk loop and
+ * stores the two differences: the clock under exactly that load, with whatever the GPU's other
+ * streams are running.  (Round 3 read the clock with a one-wave kernel BETWEEN the heavy kernels and
+ * saw 2.43 GHz: the part clocks up the moment the matrix pipes go quiet; inside the convolutions it
+ * sustains 2.0-2.3 GHz.)  stx_clock_marks_read synchronises the stream, returns the marks recorded
+ * since the last read in MHz, launch order (*n_values <= max_values; at most 16384 are kept; 0
+ * for a launch whose loop was shorter than a microsecond) and clears them.  bench.py switches them
+ * on for its second, longer measurement only: the fp32 MFMA peak scales with this clock, which
+ * depends on the kernels AND on their operands' bits.  With stx_profile_enable on as well,
+ * stx_profile_read carries the mark of each convolution group as a fourth column. */
 int stx_clock_marks(stx_engine *e, int on);
 int stx_clock_marks_read(stx_engine *e, double *mhz, int max_values, int *n_values);
 

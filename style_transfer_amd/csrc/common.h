@@ -126,6 +126,10 @@ struct ConvProblem {
                                      // wino2_fuses_pool)
     float *splitk_ws = nullptr;      // scratch for split-K partial sums (optional)
     size_t splitk_ws_floats = 0;
+    // stx_clock_marks: one workgroup of the launch (the eight-wave Winograd kernel only) stores
+    // {core-clock cycles, 100 MHz ticks} spent in its chunk loop here -- the shader clock the part
+    // sustains INSIDE the kernel that does 80 % of the work (null: nothing is read or stored)
+    long long *clock_out = nullptr;
 #ifdef STX_EXPERIMENT_BF3
     const void *x_split = nullptr;   // tools/experiments/conv_bf3.hip only
 #endif
@@ -178,6 +182,7 @@ struct WinoArgs {
     int skip_y = 0;                             // forward + fused pooling with codes: y is not stored
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
+    long long *clock_out = nullptr;             // ConvProblem::clock_out
 #ifdef STX_EXPERIMENT_BF3
     int vp_rows = 0, vp_tp = 0;                 // tools/experiments/conv_bf3.hip only
 #endif
@@ -278,7 +283,6 @@ int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef, bool accumulate);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
-int clock_mark_launch(hipStream_t s, long long *out, long long ticks);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
 int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,
                          float *out_b);

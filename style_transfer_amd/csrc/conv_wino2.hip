@@ -40,6 +40,7 @@ namespace stx {
 
 #ifdef STX_WINO2_TIMING   // cycle counters for tools/ubench/wino2_bench.hip
 __device__ long long g_wino2_timing[8][8];
+__device__ unsigned long long g_wino2_sums[8];   // over ALL workgroups (wave 0): see the end of the kernel
 #define STX_T(var) const long long var = clock64()
 #define STX_TW(var) const long long var = wall_clock64()
 #else
@@ -414,6 +415,14 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     [[maybe_unused]] long long t_work = 0;
     STX_T(t_begin);
     STX_TW(w_begin);
+    // stx_clock_marks: the workgroup in the middle of the launch times its chunk loop with both
+    // counters (a uniform branch; nothing is read when the pointer is null)
+    const bool mark = a.clock_out != nullptr && (int)blockIdx.x == (int)(gridDim.x >> 1);
+    long long mark_c = 0, mark_w = 0;
+    if (mark) {
+        mark_c = clock64();
+        mark_w = wall_clock64();
+    }
     // two chunks per trip: the LDS buffer index is a constant in each half, so every LDS address
     // of the hand-over and of the operand reads is a register plus an immediate
     // k-step 0 operands of the first chunk; from then on every chunk leaves those of its
@@ -437,6 +446,13 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     }
     STX_T(t_main_end);
     STX_TW(w_main_end);
+    if (mark) {
+        const long long dc = clock64() - mark_c, dw = wall_clock64() - mark_w;
+        if (tid == 0) {       // (loops shorter than a microsecond say nothing about the clock)
+            a.clock_out[0] = dw >= 100 ? dc : 0;
+            a.clock_out[1] = dw >= 100 ? dw : 0;
+        }
+    }
     if (chunk + 1 < c_end) {
         run_chunk(cur, chunk, yes{}, no{});
         cur ^= 1;
@@ -736,6 +752,17 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         g_wino2_timing[wave][6] = t_loads - t_start, g_wino2_timing[wave][7] = t_stored - t_loads;
         g_wino2_timing[wave][5] = clock64() - t_main_end;
     }
+    if (wave == 0 && lane == 0) {      // sums over every workgroup of the launch
+        const long long t_end = clock64();
+        atomicAdd(&g_wino2_sums[0], 1ull);
+        atomicAdd(&g_wino2_sums[1], (unsigned long long)(t_loads - t_start));     // index setup
+        atomicAdd(&g_wino2_sums[2], (unsigned long long)(t_stored - t_loads));    // first chunk: loads -> LDS
+        atomicAdd(&g_wino2_sums[3], (unsigned long long)(t_begin - t_stored));    // hand-over before the loop
+        atomicAdd(&g_wino2_sums[4], (unsigned long long)(t_main_end - t_begin));  // chunk loop (all but the last two)
+        atomicAdd(&g_wino2_sums[5], (unsigned long long)(t_end - t_main_end));    // last two chunks + epilogue
+        atomicAdd(&g_wino2_sums[6], (unsigned long long)(t_end - t_start));
+        atomicAdd(&g_wino2_sums[7], (unsigned long long)(wall_clock64() - w_begin));   // 100 MHz ticks from loop start
+    }
 #endif
 }
 
@@ -931,6 +958,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     // ReLU sign nibbles (see ConvProblem): written by the plain forward kernel, read by the plain
     // backward kernels; K slices and the BIG variants keep the fp32 mask
     const bool codes = conv_uses_relu_codes(cfg, p, split ? ksplit : 1) && !big;
+    a.clock_out = p.clock_out;
     a.in_codes = codes && p.epilogue == kEpiForward ? p.in_codes : nullptr;
     a.mask_codes = codes && p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
     const bool mk = a.mask_codes != nullptr || a.in_codes != nullptr;

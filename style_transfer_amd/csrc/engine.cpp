@@ -134,9 +134,9 @@ using namespace stx;
 struct stx_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool clock_marks = false;              // stx_clock_marks: two marks per tile evaluation
+    bool clock_marks = false;              // stx_clock_marks: one mark per 2-D Winograd launch
     DevBuf marks_buf;
-    int marks_used = 0;
+    int marks_used = 0, last_mark = -1;    // (last_mark: the slot of the launch just queued, or -1)
     std::vector<std::unique_ptr<DevBuf>> sgrad_tap;   // S = sym(D) F of every style tap
     // start / stop of the last few tile calls (a ring: stx_last_tile_ms reports the newest call
     // that has finished, so a host that runs ahead does not wait for the call it just queued)
@@ -191,6 +191,7 @@ struct stx_engine {
         std::string label;
         double flops;
         hipEvent_t start, stop;
+        int mark = -1;      // clock mark of the group's convolution launch (stx_clock_marks), or -1
     };
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -235,7 +236,10 @@ struct ProfScope {
         index = (int)e->prof.size() - 1;
     }
     ~ProfScope() {
-        if (index >= 0) (void)hipEventRecord(e->prof[index].stop, stream);
+        if (index < 0) return;
+        (void)hipEventRecord(e->prof[index].stop, stream);
+        e->prof[index].mark = e->last_mark;
+        e->last_mark = -1;
     }
 };
 
@@ -464,7 +468,16 @@ int attach_splitk(stx_engine *e, const ConvConfig &cfg, ConvProblem &p) {
     return STX_OK;
 }
 
-int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &p) {
+constexpr int kMaxClockMarks = 16384;
+
+int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &problem) {
+    ConvProblem p = problem;
+    // stx_clock_marks: the eight-wave Winograd kernel times the chunk loop of one of its workgroups
+    e->last_mark = -1;
+    if (e->clock_marks && cfg.id >= 200 && cfg.id < 210 && e->marks_used < kMaxClockMarks) {
+        e->last_mark = e->marks_used++;
+        p.clock_out = static_cast<long long *>(e->marks_buf.ptr) + 2 * (size_t)e->last_mark;
+    }
     // bookkeeping for stx_last_tile_flops: algorithmic = direct convolution, issued = what the
     // chosen kernel puts on the matrix cores (tile padding not counted)
     const double direct = 2.0 * p.M * p.K * p.ksize * p.ksize * (double)p.H * p.W;
@@ -1387,15 +1400,6 @@ int sc_grad_prepare(stx_engine *e, const TileCall &c, TilePlan &plan) {
     return shape_blobs(e, c.th, c.tw, needed, true);
 }
 
-constexpr int kMaxClockMarks = 8192;
-
-// stx_clock_marks: after the forward pass and at the end of the backward pass
-int clock_mark(stx_engine *e) {
-    if (!e->clock_marks || e->marks_used >= kMaxClockMarks) return STX_OK;
-    long long *out = static_cast<long long *>(e->marks_buf.ptr) + 2 * (size_t)e->marks_used++;
-    return clock_mark_launch(e->stream, out, 2000);
-}
-
 // Enqueues the evaluation proper: forward pass with the loss terms of the tapped blobs, backward
 // walk, the mirror copy of the loss scalars.  The tile is already in the input blob; the gradient
 // is left in its diff.
@@ -1518,7 +1522,6 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     std::vector<char> observed(e->blobs.size(), 0);
     for (const Tap &tp : order) observed[tp.blob] = 1;
     STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true, &observed));
-    STX_TRY(clock_mark(e));
     if (!interleave) {
         // (shallowest tap first, the order the interleaved schedule queues them in: the host adds
         // the loss terms up in queueing order, in double precision, and must get the same bits)
@@ -1602,7 +1605,6 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             STX_TRY(inject((size_t)k, written));
         }
     }
-    STX_TRY(clock_mark(e));
     STX_TRY(end_timing(e));
     // mirror the scalars used so far (small) for the loss
     STX_HIP(hipMemcpyAsync(e->A().host, e->A().scalars.ptr, e->A().used * sizeof(float),
@@ -2087,11 +2089,17 @@ int stx_profile_read(stx_engine *e, char *buf, size_t buf_len, size_t *needed) {
     STX_TRY(e->set_device());
     STX_HIP(hipStreamSynchronize(e->stream));
     std::string out;
+    std::vector<long long> marks((size_t)e->marks_used * 2);
+    if (!marks.empty())
+        STX_HIP(hipMemcpy(marks.data(), e->marks_buf.ptr, marks.size() * sizeof(long long), hipMemcpyDeviceToHost));
     for (auto &pe : e->prof) {
         float ms = 0.f;
         STX_HIP(hipEventElapsedTime(&ms, pe.start, pe.stop));
+        double mhz = 0.0;      // the shader clock inside the group's convolution kernel (stx_clock_marks)
+        if (pe.mark >= 0 && (size_t)pe.mark * 2 + 1 < marks.size() && marks[2 * pe.mark + 1] > 0)
+            mhz = (double)marks[2 * pe.mark] / (double)marks[2 * pe.mark + 1] * 100.0;
         char line[256];
-        snprintf(line, sizeof line, "%s\t%.6f\t%.6e\n", pe.label.c_str(), ms, pe.flops);
+        snprintf(line, sizeof line, "%s\t%.6f\t%.6e\t%.1f\n", pe.label.c_str(), ms, pe.flops, mhz);
         out += line;
         e->event_pool.push_back(pe.start);
         e->event_pool.push_back(pe.stop);
@@ -2132,7 +2140,10 @@ int stx_last_tile_ms(stx_engine *e, float *ms) {
 int stx_clock_marks(stx_engine *e, int on) {
     if (!e) return STX_ERR_ARG;
     STX_TRY(e->set_device());
-    if (on) STX_TRY(e->marks_buf.ensure((size_t)kMaxClockMarks * 2 * sizeof(long long)));
+    if (on) {
+        STX_TRY(e->marks_buf.ensure((size_t)kMaxClockMarks * 2 * sizeof(long long)));
+        STX_HIP(hipMemsetAsync(e->marks_buf.ptr, 0, (size_t)kMaxClockMarks * 2 * sizeof(long long), e->stream));
+    }
     e->clock_marks = on != 0;
     return STX_OK;
 }

@@ -154,34 +154,6 @@ __global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__
     }
 }
 
-// The shader clock at this point of a stream (stx_clock_marks): lane 0 of ONE wave reads the core-
-// cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime), dozes for `ticks` of
-// the latter (20 us), reads both again and stores the two differences.
-__global__ void clock_mark_kernel(long long *out, long long ticks) {
-    if (threadIdx.x) return;
-    // the two counters are read in the same order at both ends, so that the latency of a read
-    // cancels out of the two differences
-    long long c0 = clock64();
-    asm volatile("" : "+s"(c0));
-    const long long w0 = wall_clock64();
-    long long c1, w1;
-    do {
-        __builtin_amdgcn_s_sleep(8);
-        c1 = clock64();
-        asm volatile("" : "+s"(c1));
-        w1 = wall_clock64();
-    } while (w1 - w0 < ticks);
-    out[0] = c1 - c0;
-    out[1] = w1 - w0;
-}
-
-int clock_mark_launch(hipStream_t s, long long *out, long long ticks) {
-    clock_mark_kernel<<<1, 64, 0, s>>>(out, ticks);
-    STX_CHECK_LAUNCH();
-    return STX_OK;
-}
-
-
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef,
                           bool accumulate) {

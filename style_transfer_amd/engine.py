@@ -395,14 +395,17 @@ class TileEngine:
         """Turns per-kernel-group event timing on or off (clears the record)."""
         lib.call('stx_profile_enable', self.handle, int(on))
 
-    def profile_read(self):
-        """[(label, milliseconds, algorithmic flops)] recorded since the last read."""
+    def profile_read(self, clock=False):
+        """[(label, milliseconds, algorithmic flops)] recorded since the last read; with
+        ``clock=True`` a fourth field: the shader clock in MHz inside the group's convolution kernel
+        (0 unless clock_marks is on and the group is a 2-D Winograd launch)."""
         buf = ctypes.create_string_buffer(1 << 20)
         lib.call('stx_profile_read', self.handle, buf, len(buf), None)
         rows = []
         for line in buf.value.decode().splitlines():
-            label, ms, flops = line.split('\t')
-            rows.append((label, float(ms), float(flops)))
+            label, ms, flops, mhz = line.split('\t')
+            rows.append((label, float(ms), float(flops), float(mhz)) if clock else
+                        (label, float(ms), float(flops)))
         return rows
 
     def last_tile_flops(self):

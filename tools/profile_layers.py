@@ -23,20 +23,26 @@ for _ in range(2):
     eng.sc_grad_tile_async(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw, grad_out=grad)
 eng.sync()
 eng.profile(True)
+eng.clock_marks(True)      # the shader clock inside every 2-D Winograd launch (4th column)
 acc = {}
 order = []
 for _ in range(reps):
     eng.sc_grad_tile_async(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw, grad_out=grad)
-    for label, ms, flops in eng.profile_read():
+    for label, ms, flops, mhz in eng.profile_read(clock=True):
         if label not in acc:
-            acc[label] = [0.0, flops]
+            acc[label] = [0.0, flops, 0.0, 0]
             order.append(label)
         acc[label][0] += ms
+        if mhz > 0:
+            acc[label][2] += mhz
+            acc[label][3] += 1
+    eng.clock_marks_read()
 tot_ms = tot_fl = 0
-print('%-18s %9s %9s %8s' % ('group', 'ms', 'GFLOP', 'TFLOP/s'))
+print('%-18s %9s %9s %8s %8s' % ('group', 'ms', 'GFLOP', 'TFLOP/s', 'MHz'))
 for label in order:
     ms, fl = acc[label][0] / reps, acc[label][1]
     tot_ms += ms
     tot_fl += fl
-    print('%-18s %9.3f %9.1f %8.1f' % (label, ms, fl / 1e9, fl / ms / 1e9 if fl else 0))
+    print('%-18s %9.3f %9.1f %8.1f %8s' % (label, ms, fl / 1e9, fl / ms / 1e9 if fl else 0,
+                                           '%.0f' % (acc[label][2] / acc[label][3]) if acc[label][3] else ''))
 print('%-18s %9.3f %9.1f %8.1f' % ('TOTAL (events)', tot_ms, tot_fl / 1e9, tot_fl / tot_ms / 1e9))

@@ -63,6 +63,13 @@ static void run(int K, int M, int H, int W, int epilogue) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) wino2_launch(0, cfg, p, 1);
+#ifdef STX_WINO2_TIMING
+    {
+        unsigned long long zero[8] = {0};
+        hipDeviceSynchronize();
+        hipMemcpyToSymbol(HIP_SYMBOL(stx::g_wino2_sums), zero, sizeof(zero));
+    }
+#endif
     hipEventRecord(e0);
     const int reps = 10;
     for (int i = 0; i < reps; ++i) wino2_launch(0, cfg, p, 1);
@@ -85,6 +92,15 @@ static void run(int K, int M, int H, int W, int epilogue) {
     }
 #endif
 #ifdef STX_WINO2_TIMING
+    if (cfg.id < 210) {
+        unsigned long long sm[8];
+        hipMemcpyFromSymbol(sm, HIP_SYMBOL(stx::g_wino2_sums), sizeof(sm));
+        const double n = (double)sm[0];
+        printf("   mean over %.0f workgroups: setup %5.0f  first loads -> LDS %5.0f  hand-over %5.0f  chunk loop %6.0f (%.0f per chunk)  "
+               "last two chunks + epilogue %6.0f  = %6.0f cycles per workgroup; x %d workgroups / 256 CUs / %.3f ms = %.0f MHz\n",
+               n, sm[1] / n, sm[2] / n, sm[3] / n, sm[4] / n, sm[4] / n / std::max(1, (K + 7) / 8 - 2), sm[5] / n, sm[6] / n,
+               (int)(n / reps), ms, sm[6] / n * (n / reps) / 256.0 / (ms * 1e3));
+    }
     long long t[8][8];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(stx::g_wino2_timing), sizeof(t));
     const int chunks = (K + 7) / 8 - 2;
