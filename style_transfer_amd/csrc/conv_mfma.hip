@@ -905,7 +905,19 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
     // 16-row patches (10 % of halo rows, 0.75 LDS reads per MFMA) where the plane still yields a
     // few workgroups per CU; 8-row patches (25 %, 1.2) on small planes
     const bool tall = (long)a.tiles_x * ceil_div(H, kSmallPR) >= 1024;
-    const int pr = tall ? kSmallPR : kSmallPR / 2;
+    int pr = tall ? kSmallPR : kSmallPR / 2;
+#ifdef STX_SMALL_SWEEP      // tuning aid (tools/bench_small.py): STX_SMALL_TUNE=<KC><PR code>, identical results
+    if (const char *tune = getenv("STX_SMALL_TUNE")) {
+        const int kc = atoi(tune) / 100, prr = atoi(tune) % 100;
+        a.n_chunks = ceil_div(K, kc);
+        a.n_wg = a.tiles_x * ceil_div(H, prr);
+        a.wg_per_xcd = ceil_div(a.n_wg, 8);
+        const int g = a.wg_per_xcd * 8;
+#define STX_SWEEP(KC_, PR_) if (kc == KC_ && prr == PR_) { conv3x3_m4_kernel<KC_, PR_, true><<<g, 256, 0, s>>>(a); STX_CHECK_LAUNCH(); return STX_OK; }
+        STX_SWEEP(4, 8) STX_SWEEP(4, 16) STX_SWEEP(4, 32) STX_SWEEP(8, 8) STX_SWEEP(8, 16) STX_SWEEP(8, 32) STX_SWEEP(16, 8) STX_SWEEP(16, 16)
+#undef STX_SWEEP
+    }
+#endif
     a.n_wg = a.tiles_x * ceil_div(H, pr);
     a.wg_per_xcd = ceil_div(a.n_wg, 8);
     const int grid = a.wg_per_xcd * 8;

@@ -37,9 +37,7 @@
 
 // (round 4: moved out of libstx.so; compile with -DSTX_EXPERIMENT_BF3, which restores the two
 // fields of ConvProblem / WinoArgs this kernel used; tools/ubench/bf3conv_bench.hip does)
-#ifndef STX_EXPERIMENT_BF3
-#error "compile with -DSTX_EXPERIMENT_BF3"
-#endif
+#ifdef STX_EXPERIMENT_BF3      // (without it this file compiles to nothing)
 #include "bf16x3.h"
 #include "common.h"
 
@@ -652,3 +650,4 @@ int bf3_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int k
 }
 
 }  // namespace stx
+#endif  // STX_EXPERIMENT_BF3
