@@ -40,6 +40,34 @@ __device__ __forceinline__ void block_partials(float (&v)[NV], float *partials) 
     }
 }
 
+// (c, y, x) of flat index i of a [3][H][W] array, carried along a grid-stride loop with adds and
+// compares: the three 64-bit divisions per element that `i % W`, `i / W % H`, `i / plane` cost were
+// most of the regularizer and statistics kernels' instructions (93 and 50 us on a 2048^2 image).
+// Same elements in the same order per thread: the sums are bit-identical to the division form's.
+struct Pos3 {
+    int x, y, c;
+};
+struct Stride3 {
+    int sx, sy, sc;      // the loop stride gridDim.x * 256 as (columns, rows, planes)
+};
+__device__ __forceinline__ Pos3 pos3_at(size_t i, int H, int W) {
+    const size_t row = i / (size_t)W;
+    return Pos3{(int)(i - row * (size_t)W), (int)(row % (size_t)H), (int)(row / (size_t)H)};
+}
+__device__ __forceinline__ Stride3 stride3_of(size_t stride, int H, int W) {
+    const size_t rows = stride / (size_t)W;
+    return Stride3{(int)(stride - rows * (size_t)W), (int)(rows % (size_t)H), (int)(rows / (size_t)H)};
+}
+__device__ __forceinline__ void pos3_advance(Pos3 &p, const Stride3 &s, int H, int W) {
+    p.x += s.sx;
+    const int cx = p.x >= W ? 1 : 0;
+    p.x -= cx ? W : 0;
+    p.y += s.sy + cx;
+    const int cy = p.y >= H ? 1 : 0;
+    p.y -= cy ? H : 0;
+    p.c += s.sc + cy;
+}
+
 // out[k] = sum over n partials of value k, accumulated in double in a fixed order.
 template <int NV>
 __global__ void finish_partials_kernel(const float *__restrict__ partials, int n,
@@ -91,14 +119,56 @@ __global__ __launch_bounds__(256) void tile_move_kernel(float *__restrict__ full
 
 static dim3 tile_move_grid(int th, int tw) { return dim3((unsigned)std::min(8, (tw + 255) / 256), (unsigned)(3 * th)); }
 
+// The same move four columns at a time (16-byte accesses): widths, the tile's first source column
+// and both bases multiples of four floats -- which the seam-suppression shifts are (multiples of
+// the deepest content layer's scale, 8 or 16: style_transfer.py:777-779) -- so a group of four
+// never straddles the wrap.  Four rows per workgroup: a quarter of a million one-dword threads
+// per 1024^2 tile made the copy launch-bound (13 us for 25 MB).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool PUT>
+__global__ __launch_bounds__(256) void tile_move4_kernel(float *__restrict__ full, int H, int W,
+                                                         int rx, int ry, int y0, int x0, int th,
+                                                         int tw, float *__restrict__ tile) {
+    const int tw4 = tw >> 2, per_row = (tw4 + 63) / 64 * 64;      // lanes per row, whole waves
+    const int rows = 3 * th;
+    const int xs = wrap(x0 - rx, W);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * per_row; e += gridDim.x * 256) {
+        const int cy = e / per_row, x4 = e - cy * per_row;
+        if (x4 >= tw4) continue;
+        const int c = cy / th, y = cy - c * th;
+        float *const frow = full + ((size_t)c * H + wrap(y0 + y - ry, H)) * W;
+        float *const trow = tile + (size_t)cy * tw;
+        int xx = xs + 4 * x4;
+        xx = xx >= W ? xx - W : xx;
+        if (PUT)
+            *reinterpret_cast<f32x4_t *>(frow + xx) = *reinterpret_cast<const f32x4_t *>(trow + 4 * x4);
+        else
+            *reinterpret_cast<f32x4_t *>(trow + 4 * x4) = *reinterpret_cast<const f32x4_t *>(frow + xx);
+    }
+}
+
+static bool tile_move_vec(const float *full, int W, int rx, int x0, int tw, const float *tile) {
+    const int xs = ((x0 - rx) % W + W) % W;      // (host-side twin of wrap())
+    return tw % 4 == 0 && W % 4 == 0 && tw <= W && xs % 4 == 0 &&
+           ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(tile)) & 15) == 0;
+}
+static int tile_move4_blocks(int th, int tw) {
+    const long lanes = 3L * th * (((tw >> 2) + 63) / 64 * 64);
+    return (int)std::min<long>((lanes + 255) / 256, 4096);
+}
+
 int cut_tile_launch(hipStream_t s, const float *img, int H, int W, int rx, int ry, int y0, int x0,
                     int th, int tw, float *tile) {
     if (3 * (long)th > 65535) {
         set_error("cut_tile: tile of %d rows is too tall", th);
         return STX_ERR_UNSUPPORTED;
     }
-    tile_move_kernel<false><<<tile_move_grid(th, tw), 256, 0, s>>>(const_cast<float *>(img), H, W, rx, ry, y0,
-                                                                  x0, th, tw, tile);
+    if (tile_move_vec(img, W, rx, x0, tw, tile))
+        tile_move4_kernel<false><<<tile_move4_blocks(th, tw), 256, 0, s>>>(const_cast<float *>(img), H, W, rx,
+                                                                            ry, y0, x0, th, tw, tile);
+    else
+        tile_move_kernel<false><<<tile_move_grid(th, tw), 256, 0, s>>>(const_cast<float *>(img), H, W, rx, ry,
+                                                                      y0, x0, th, tw, tile);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
@@ -109,8 +179,12 @@ int put_tile_launch(hipStream_t s, float *grad, int H, int W, int rx, int ry, in
         set_error("put_tile: tile of %d rows is too tall", th);
         return STX_ERR_UNSUPPORTED;
     }
-    tile_move_kernel<true><<<tile_move_grid(th, tw), 256, 0, s>>>(grad, H, W, rx, ry, y0, x0, th, tw,
-                                                                 const_cast<float *>(tile));
+    if (tile_move_vec(grad, W, rx, x0, tw, tile))
+        tile_move4_kernel<true><<<tile_move4_blocks(th, tw), 256, 0, s>>>(grad, H, W, rx, ry, y0, x0, th, tw,
+                                                                           const_cast<float *>(tile));
+    else
+        tile_move_kernel<true><<<tile_move_grid(th, tw), 256, 0, s>>>(grad, H, W, rx, ry, y0, x0, th, tw,
+                                                                     const_cast<float *>(tile));
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
@@ -228,10 +302,11 @@ struct RegArgs {
 __global__ __launch_bounds__(256) void regularizers_kernel(RegArgs a, float *__restrict__ partials) {
     const size_t plane = (size_t)a.H * a.W, total = 3 * plane;
     float sums[3] = {0.f, 0.f, 0.f};   // TV, P, AUX (unscaled)
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = i % a.W;
-        const int y = (i / a.W) % a.H;
-        const int c = i / plane;
+    const size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+    Pos3 pos = pos3_at(i0, a.H, a.W);
+    const Stride3 step = stride3_of((size_t)gridDim.x * 256, a.H, a.W);
+    for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256, pos3_advance(pos, step, a.H, a.W)) {
+        const int x = pos.x, y = pos.y, c = pos.c;
         const float *p = a.img + (size_t)c * plane;
         const float v = p[(size_t)y * a.W + x];
         float g = a.grad[i];   // each term is added like a separate saxpy (style_transfer.py:713-733)
@@ -553,9 +628,11 @@ __global__ __launch_bounds__(256) void step_stats_kernel(const float *__restrict
                                                          float *__restrict__ partials) {
     const size_t plane = (size_t)H * W, total = 3 * plane;
     float sums[2] = {0.f, 0.f};
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int x = i % W;
-        const int y = (i / W) % H;
+    const size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x;
+    Pos3 pos = pos3_at(i0, H, W);
+    const Stride3 step = stride3_of((size_t)gridDim.x * 256, H, W);
+    for (size_t i = i0; i < total; i += (size_t)gridDim.x * 256, pos3_advance(pos, step, H, W)) {
+        const int x = pos.x, y = pos.y;
         const size_t base = i - (size_t)y * W - x;
         const float v = avg[i];
         sums[0] += fabsf(v - old[i]);
