@@ -2,7 +2,8 @@
 scales of the `--size 2048 --tile-size 1024` pyramid, through TileFarm (the product path), with
 the GPU span of the tile evaluation (HIP events) and the host's queueing cost beside it.
 
-    python tools/scale_steps.py [sizes...]
+    python tools/scale_steps.py [sizes...]        STX_RUN_AHEAD=0: the blocking loop (every step collected
+                                                  before the next is queued) instead of the product's run-ahead loop
 """
 import os
 import sys
@@ -35,6 +36,9 @@ for size in sizes:
     opt = AdamOptimizer(eng, img, step_size=15, bp1=0.95, decay=0.05, power=0.5)
     st = np.random.RandomState(1)
 
+    ahead = os.environ.get('STX_RUN_AHEAD', '1') != '0'
+    in_flight = []
+
     def step():
         roll = np.int32(st.uniform(-0.5, 0.5, size=2) * size) // 8 * 8
 
@@ -43,15 +47,30 @@ for size in sizes:
             loss.add(image_ops.regularizers(eng, p, grad, MEAN, 5.0, 2.0, 2.0, 6.0), eng)
             return loss, grad
         avg, loss = opt.update(opfunc)
-        image_ops.step_stats(eng, avg, old)
-        return float(loss)
+        if not ahead:
+            image_ops.step_stats(eng, avg, old)
+            return float(loss)
+        # StyleTransfer.transfer's loop: queue this step, then collect the previous one
+        stats = image_ops.step_stats_async(eng, avg, old)
+        loss.seal(also=[eng])
+        if in_flight:
+            l, s_ = in_flight.pop()
+            float(l), s_.values()
+        in_flight.append((loss, stats))
+
+    def drain():
+        while in_flight:
+            l, s_ = in_flight.pop()
+            float(l), s_.values()
 
     for _ in range(5):
         step()
+    drain()
     n = 60
     t0 = time.perf_counter()
     for _ in range(n):
         step()
+    drain()
     dt = (time.perf_counter() - t0) / n * 1e3
     tiles = farm.tile_evals
     gpu = max(e.last_tile_ms() for e in farm.engines[:max(1, min(4, ((size - 1) // 1024 + 1) ** 2))])
