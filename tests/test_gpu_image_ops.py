@@ -173,3 +173,67 @@ def test_swt_haar_term_against_oracle(shape, roll, power):
     eng.sync()
     assert out.value == pytest.approx(scale * loss, rel=2e-5)
     assert np.abs(d_grad.get() - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def test_cut_and_put_tile_sixteen_byte_path_equals_roll_then_slice():
+    """Widths, tile origin and shift multiples of four floats take the 16-byte kernel
+    (tile_move4_kernel); anything else the dword one.  Both are roll2 + slice
+    (style_transfer.py:619-643, num_utils.py:136-140), bit for bit, wrap included."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(15)
+    img = rng.standard_normal((3, 40, 96)).astype(np.float32)
+    d_img = eng.to_device(img)
+    for roll in [(0, 0), (8, -16), (-52, 36), (200, -74), (6, 3)]:       # the last one: dword path
+        for rect in [(0, 24, 0, 48), (8, 40, 48, 96), (4, 36, 32, 96)]:
+            th, tw = rect[1] - rect[0], rect[3] - rect[2]
+            rolled = num_ops.roll_xy(img.copy(), roll)
+            tile = eng.empty((3, th, tw))
+            image_ops.cut_tile(eng, d_img, roll, rect, tile)
+            assert np.array_equal(tile.get(), rolled[:, rect[0]:rect[1], rect[2]:rect[3]]), (roll, rect)
+            full = eng.empty(img.shape).zero()
+            image_ops.put_tile(eng, full, roll, rect, tile)
+            expect = np.zeros_like(img)
+            expect[:, rect[0]:rect[1], rect[2]:rect[3]] = rolled[:, rect[0]:rect[1], rect[2]:rect[3]]
+            assert np.array_equal(full.get(), num_ops.roll_xy(expect, (-roll[0], -roll[1]))), (roll, rect)
+            tile.free()
+            full.free()
+
+
+def test_fences_publish_exactly_what_they_closed():
+    """stx_fence / stx_fence_wait (the run-ahead step loop): values queued before a fence are
+    published by waiting for that fence -- or earlier, when a second fence has to reuse their set
+    -- and never depend on work queued after it; asynchronous step statistics equal the
+    synchronous ones."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(16)
+    imgs = [rng.uniform(-100, 100, (3, 32, 48)).astype(np.float32) for _ in range(3)]
+    d = [eng.to_device(a) for a in imgs]
+    grads = [eng.empty(a.shape).zero() for a in imgs]
+    want = []
+    for a, g in zip(d, grads):
+        r = image_ops.regularizers(eng, a, g, MEAN, 5.0, 2.0, 2.0, 6.0)
+        eng.sync()
+        want.append(r.value)
+        g.zero()
+    eng.sync()
+    # three values behind three fences; the third fence reuses the first one's set
+    pending, tickets = [], []
+    for a, g in zip(d, grads):
+        pending.append(image_ops.regularizers(eng, a, g, MEAN, 5.0, 2.0, 2.0, 6.0))
+        tickets.append(eng.fence())
+    assert pending[0].value == want[0]                 # published when its set was needed again
+    assert np.isnan(pending[2].value)
+    eng.wait_fence(tickets[0])                          # (an old ticket: nothing to do)
+    eng.wait_fence(tickets[2])
+    assert pending[2].value == want[2]
+    eng.wait_fence(tickets[1])
+    assert pending[1].value == want[1]
+    # statistics: the asynchronous form against the synchronous one
+    avg = rng.uniform(-140, 160, (3, 33, 41)).astype(np.float32)
+    old = rng.uniform(-140, 160, (3, 33, 41)).astype(np.float32)
+    d_avg, d_old, d_old2 = eng.to_device(avg), eng.to_device(old), eng.to_device(old)
+    sync_stats = image_ops.step_stats(eng, d_avg, d_old)
+    lazy = image_ops.step_stats_async(eng, d_avg, d_old2)
+    eng.wait_fence(eng.fence())
+    assert lazy.values() == sync_stats
+    assert np.array_equal(d_old2.get(), avg)
