@@ -415,12 +415,14 @@ class TileEngine:
         return a.value, b.value
 
     def clock_marks(self, on):
-        """While on, every sc_grad_tile records the shader clock at two points of its stream
-        (stx_clock_marks: 20-microsecond one-wave kernels)."""
+        """While on, one workgroup of every 2-D Winograd convolution launch of this engine times its
+        chunk loop with the core-cycle counter and the constant 100 MHz counter (stx_clock_marks):
+        the shader clock inside the kernel that does most of the work."""
         lib.call('stx_clock_marks', self.handle, 1 if on else 0)
 
-    def clock_marks_read(self, max_values=8192):
-        """MHz of the marks recorded since the last read (synchronises this engine's stream)."""
+    def clock_marks_read(self, max_values=16384):
+        """MHz of the marks recorded since the last read, launch order (0: a loop too short to
+        tell); synchronises this engine's stream and clears the record."""
         mhz = (ctypes.c_double * max_values)()
         n = ctypes.c_int(0)
         lib.call('stx_clock_marks_read', self.handle, mhz, max_values, ctypes.byref(n))
