@@ -23,6 +23,7 @@ SOURCES = {
     'conv_wino.hip': [],
     'conv_wino2.hip': [],
     'conv_wino4.hip': [],
+    'conv_first.hip': [],
     'gram.hip': [],
     'symm.hip': [],
     'pool.hip': [],

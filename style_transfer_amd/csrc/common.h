@@ -198,6 +198,14 @@ int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int t
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
 
+// First layer (at most 3 planes -> 64 channels, 3x3) with the Gram partials of its own output
+// (conv_first.hip).  gram_partials (or null): conv_first_workgroups(H, W) partial tiles of 64 x 64
+// floats, finished by gram_finish_launch with {C 64, HW, splits = that count, tiles 1, parts 1}.
+bool conv_first_usable(int K, int M, int ksize);
+int conv_first_workgroups(int H, int W);
+int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const float *bias, float *y,
+                      int K, int H, int W, int relu, float *gram_partials);
+
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
 ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16, 2: 8 x 32
 int wino2_pick_geometry(int H, int W);

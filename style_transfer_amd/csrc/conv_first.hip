@@ -1,0 +1,275 @@
+// First layer of the network (3 -> 64 channels, 3 x 3, pad 1; conv1_1 of VGG-16 / VGG-19) with the
+// Gram partials of its own output.
+//
+// The layer is all output: 268 MB written for 12.6 MB read on a 1024 x 1024 tile, 3.8 GFLOP -- and
+// the first thing anybody does with the blob is read all of it again for its Gram matrix (the
+// shallowest style tap, style_transfer.py:584-590).  This kernel keeps a tile of the blob on chip
+// for that: a workgroup walks 128-pixel row segments; per segment
+//   * the 3 x 3 x 130 input patch sits in LDS (next segment's patch is in flight in registers);
+//   * wave w computes pixels 32 w .. 32 w + 31 for all 64 channels: D[64][32] = W[64][27] X[27][32]
+//     as 2 x 14 v_mfma_f32_32x32x2_f32 with the filter bank resident in registers, + bias, ReLU;
+//   * the 64 x 128 result goes to LDS as [channel][pixel]; from there it is stored with 16-byte
+//     row segments, and -- GRAM -- read back as the bf16 MFMA's fragments (8 consecutive pixels of a
+//     channel per lane), split into three bf16 pieces and multiplied into the workgroup's running
+//     64 x 64 Gram tile exactly as gram_partial_bf3_kernel does (bf16x3.h: six exact products per
+//     pair, fp32-class accuracy), wave w taking pixels 32 w .. 32 w + 31 as two 16-pixel steps.
+// At the end the four waves' tiles are added in wave order and written as ONE partial tile per
+// workgroup, in the layout gram_finish_kernel reads (splits = workgroups, one tile).  Segments are
+// dealt out statically (workgroup b takes b, b + grid, ...): every sum has a fixed order.
+//
+// Replaces, for this shape, conv_mfma_kernel's first-layer configuration (84 us at 3.2 TB/s of
+// output on a 1024^2 tile) and gram_partial_bf3_kernel's pass over the blob (56 us, 268 MB read).
+// Reference: Caffe Convolution + in-place ReLU of conv1_1 (vgg19.prototxt), num_utils.py:143-147.
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "bf16x3.h"
+#include "common.h"
+
+namespace stx {
+
+namespace {
+
+constexpr int kFP = 128;             // pixels per segment
+constexpr int kFM = 64;              // output channels
+constexpr int kPW = kFP + 4;         // patch row in LDS: [x0 - 1 .. x0 + 128] + pad
+constexpr int kPatch = 9 * kPW;      // 3 channels x 3 rows
+constexpr int kFLd = kFP + 4;        // row of the output tile in LDS (floats)
+constexpr int kTile = kFM * kFLd;
+constexpr int kNT = 256;
+constexpr int kPL = (9 * (kFP + 2) + kNT - 1) / kNT;     // patch loads per thread (5)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FirstArgs {
+    const float *x;          // [K <= 3][H][W]
+    const float *w;          // Caffe bank [64][K][3][3]
+    const float *bias;       // [64] or null
+    float *y;                // [64][H][W]
+    float *gram;             // GRAM: one 64 x 64 partial tile per workgroup
+    int K, H, W, tiles_x, n_tiles, relu, vec_store;
+};
+
+}  // namespace
+
+template <bool GRAM>
+__global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
+    // [patch 0 | patch 1 | output tile]; after the last segment the four waves' Gram tiles
+    // (4 x 64 x 64 floats) take the whole array
+    constexpr int kWork = 2 * kPatch + kTile, kRed = 4 * kFM * kFM;
+    __shared__ __attribute__((aligned(16))) float lds[GRAM && kRed > kWork ? kRed : kWork];
+    __shared__ float bias_l[kFM];
+    float *const patch = lds;
+    float *const tile = lds + 2 * kPatch;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const size_t HW = (size_t)a.H * a.W;
+
+    // ---- the filter bank as MFMA A operands: aw[mb][s] = W[mb * 32 + l31][k = 2 s + half],
+    // k = (c, ky, kx) row-major; k >= 9 K reads as zero.  boff[s]: where k sits in the patch.
+    float aw[2][14];
+    int boff[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int k = 2 * s + half;
+        const bool live = k < 9 * a.K;
+        const int kk = live ? k : 0;
+        const int c = kk / 9, ky = (kk - 9 * c) / 3, kx = kk - 9 * c - 3 * ky;
+        boff[s] = (c * 3 + ky) * kPW + kx;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            aw[mb][s] = live ? a.w[(size_t)(mb * 32 + l31) * (9 * a.K) + k] : 0.f;
+    }
+    // (the bias in LDS: 32 registers per lane otherwise)
+    if (tid < kFM) bias_l[tid] = a.bias ? a.bias[tid] : 0.f;
+
+    // ---- patch staging: element e of the 9 x 130 patch = (plane c * 3 + row r, column col)
+    float preg[kPL];
+    auto patch_load = [&](int t) {
+        const int ty = t / a.tiles_x, x0 = (t - ty * a.tiles_x) * kFP;
+#pragma unroll
+        for (int n = 0; n < kPL; ++n) {
+            const int e = tid + n * kNT;
+            const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
+            const int c = pr / 3, r = pr - 3 * c;
+            const int yy = ty - 1 + r, xx = x0 - 1 + col;
+            const bool ok = e < 9 * (kFP + 2) && c < a.K && (unsigned)yy < (unsigned)a.H &&
+                            (unsigned)xx < (unsigned)a.W;
+            preg[n] = ok ? a.x[(size_t)c * HW + (size_t)yy * a.W + xx] : 0.f;
+        }
+    };
+    auto patch_store = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < kPL; ++n) {
+            const int e = tid + n * kNT;
+            const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
+            if (e < 9 * (kFP + 2)) patch[buf * kPatch + pr * kPW + col] = preg[n];
+        }
+    };
+
+    f32x16 g[3];       // Gram blocks (0,0), (1,0), (1,1) of this wave's pixels
+    if (GRAM) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[b][r] = 0.f;
+    }
+
+    int t = blockIdx.x;
+    if (t < a.n_tiles) {
+        patch_load(t);
+        patch_store(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; t < a.n_tiles; t += gridDim.x, buf ^= 1) {
+        const int tn = t + gridDim.x;
+        if (tn < a.n_tiles) patch_load(tn);          // in flight during this segment
+        const int ty = t / a.tiles_x, x0 = (t - ty * a.tiles_x) * kFP;
+
+        // ---- convolution: 2 channel blocks x 14 k-steps on this wave's 32 pixels
+        f32x16 acc[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+        const float *pb = patch + buf * kPatch + wave * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const float b = pb[boff[s]];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[0][s], b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[1][s], b, acc[1], 0, 0, 0);
+        }
+        // ---- bias, ReLU; pixels past the end of the row are ZERO in the tile (they take part in
+        // the Gram sums and must not: relu(bias) is not zero)
+        const int px = wave * 32 + l31;
+        const bool inside = x0 + px < a.W;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[mb][r] + bias_l[ch];
+                if (a.relu) v = fmaxf(v, 0.f);
+                v = inside ? v : 0.f;
+                tile[ch * kFLd + px] = v;
+            }
+        __syncthreads();      // the tile is complete (and everybody has left the previous segment's reads)
+
+        // ---- the blob: 16-byte row segments out of LDS
+        {
+            float *const yrow = a.y + (size_t)ty * a.W + x0;
+#pragma unroll
+            for (int n = 0; n < kFM * (kFP / 4) / kNT; ++n) {
+                const int e = tid + n * kNT;
+                const int ch = e / (kFP / 4), c4 = (e - ch * (kFP / 4)) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + ch * kFLd + c4);
+                float *const dst = yrow + (size_t)ch * HW + c4;
+                if (a.vec_store && x0 + c4 + 3 < a.W) {
+                    *reinterpret_cast<f32x4 *>(dst) = v;
+                } else {
+                    if (x0 + c4 + 0 < a.W) dst[0] = v.x;
+                    if (x0 + c4 + 1 < a.W) dst[1] = v.y;
+                    if (x0 + c4 + 2 < a.W) dst[2] = v.z;
+                    if (x0 + c4 + 3 < a.W) dst[3] = v.w;
+                }
+            }
+        }
+        // ---- Gram: this wave's 32 pixels as two 16-pixel steps
+        if (GRAM) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 p[2][3];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const float *q = tile + (mb * 32 + l31) * kFLd + wave * 32 + st * 16 + half * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4 *>(q);
+                    const f32x4 hi = *reinterpret_cast<const f32x4 *>(q + 4);
+                    const float xv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    split3_bf16(xv, p[mb][0], p[mb][1], p[mb][2]);
+                }
+                g[0] = mfma_split6(p[0], p[0], g[0]);
+                g[1] = mfma_split6(p[1], p[0], g[1]);
+                g[2] = mfma_split6(p[1], p[1], g[2]);
+            }
+        }
+        if (tn < a.n_tiles) patch_store(buf ^ 1);
+        __syncthreads();      // tile reads done; the next patch is in place
+    }
+
+    if (GRAM) {
+        // the four waves' tiles side by side, then ((w0 + w1) + w2) + w3 per element, as
+        // gram_partial_bf3_kernel adds them; block (0, 1) of the diagonal tile stays zero
+        __syncthreads();
+        float *red = lds + wave * (kFM * kFM);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[row * kFM + l31] = g[0][r];
+            red[row * kFM + 32 + l31] = 0.f;
+            red[(32 + row) * kFM + l31] = g[1][r];
+            red[(32 + row) * kFM + 32 + l31] = g[2][r];
+        }
+        __syncthreads();
+        float *out = a.gram + (size_t)blockIdx.x * (kFM * kFM);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int e = tid + kNT * n;
+            const float4 w0 = reinterpret_cast<const float4 *>(lds)[e];
+            const float4 w1 = reinterpret_cast<const float4 *>(lds + kFM * kFM)[e];
+            const float4 w2 = reinterpret_cast<const float4 *>(lds + 2 * kFM * kFM)[e];
+            const float4 w3 = reinterpret_cast<const float4 *>(lds + 3 * kFM * kFM)[e];
+            float4 v;
+            v.x = ((w0.x + w1.x) + w2.x) + w3.x;
+            v.y = ((w0.y + w1.y) + w2.y) + w3.y;
+            v.z = ((w0.z + w1.z) + w2.z) + w3.z;
+            v.w = ((w0.w + w1.w) + w2.w) + w3.w;
+            reinterpret_cast<float4 *>(out)[e] = v;
+        }
+    }
+}
+
+// The shapes this kernel takes: a 3 x 3 layer from at most three planes into exactly 64 channels.
+bool conv_first_usable(int K, int M, int ksize) {
+    const char *env = getenv("STX_CONV_FIRST_FUSED");
+    if (env && atoi(env) == 0) return false;
+    return ksize == 3 && K >= 1 && K <= 3 && M == kFM;
+}
+
+// Workgroups of a launch on an H x W plane = Gram partial tiles it leaves (two per CU, fewer on
+// small planes).
+int conv_first_workgroups(int H, int W) {
+    const long tiles = (long)H * ceil_div(W, kFP);
+    return (int)std::min<long>(tiles, 512);
+}
+
+// y = [relu](conv(x, w) + bias); gram_partials (or null): conv_first_workgroups(H, W) partial tiles
+// of 64 x 64 floats, to be finished with a GramPlan {C 64, HW, splits = that count, tiles 1}.
+int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const float *bias, float *y,
+                      int K, int H, int W, int relu, float *gram_partials) {
+    FirstArgs a;
+    a.x = x;
+    a.w = w_caffe;
+    a.bias = bias;
+    a.y = y;
+    a.gram = gram_partials;
+    a.K = K;
+    a.H = H;
+    a.W = W;
+    a.tiles_x = ceil_div(W, kFP);
+    a.n_tiles = H * a.tiles_x;
+    a.relu = relu;
+    a.vec_store = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const int grid = conv_first_workgroups(H, W);
+    if (gram_partials)
+        conv_first_kernel<true><<<grid, kNT, 0, s>>>(a);
+    else
+        conv_first_kernel<false><<<grid, kNT, 0, s>>>(a);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+}  // namespace stx

@@ -152,6 +152,11 @@ struct stx_engine {
     std::shared_ptr<SharedState> sh;   // weights, packed banks, targets (shared per GPU)
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
+    // the first layer leaves the Gram partials of its own output when that blob is a style tap of
+    // the call (conv_first.hip): which blob, whether this call's forward pass wrote them, how many
+    DevBuf first_gram;
+    int first_gram_blob = -1, first_gram_parts = 0;
+    bool first_gram_valid = false;
     DevBuf gram_partials, gram, dsym, dsym_pieces, symm_partials, upload;
     // Loss scalars of the calls queued so far: device floats (tile terms) and doubles (image-op
     // reductions), each with a pinned host mirror, and the losses that will be published from
@@ -517,6 +522,26 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     p.ksize = cp.ks;
     p.relu = (t.relu || force_relu) ? 1 : 0;
     p.epilogue = kEpiForward;
+    if (conv_first_usable(cp.cin, cp.cout, cp.ks) && !pool) {
+        // the first layer: its own kernel, straight from the Caffe-layout bank; with the Gram
+        // partials of the blob when it is a style tap of this call
+        if (pooled) *pooled = false;
+        b.relu_codes_valid = false;
+        float *gram = nullptr;
+        if (L.top_blob == e->first_gram_blob) {
+            const int parts = conv_first_workgroups(b.h, b.w);
+            // (+ room for gram_finish's per-block sums of squares behind the partial tiles)
+            STX_TRY(e->first_gram.ensure(((size_t)parts * 64 * 64 + 64 * 64 / 64 + 64) * sizeof(float)));
+            gram = e->first_gram.f();
+            e->first_gram_parts = parts;
+            e->first_gram_valid = true;
+        }
+        ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
+        const double direct = conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks);
+        e->flop_algorithmic += direct;
+        e->flop_issued += direct;
+        return conv_first_launch(e->stream, p.x, cp.w.f(), cp.b.f(), p.y, cp.cin, b.h, b.w, p.relu, gram);
+    }
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
     const float *packed = nullptr;
@@ -685,21 +710,31 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
 int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
                        const float *target, float *sgrad, float *sc, const std::string &name) {
     const int HW = h * w;
-    const GramPlan plan = gram_plan(C, HW);
+    // the first layer's kernel may have left this blob's Gram partials already (conv_first.hip)
+    const bool fused = e->first_gram_valid && e->first_gram_blob >= 0 &&
+                       feat == e->blobs[e->first_gram_blob].data.f() && C == 64;
+    GramPlan plan = gram_plan(C, HW);
+    if (fused) {
+        plan.splits = e->first_gram_parts;
+        plan.tiles = 1;
+        plan.parts = 1;
+        plan.partial_floats = (size_t)plan.splits * 64 * 64;
+    }
     const int fin_blocks = gram_finish_blocks(plan);
-    STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
+    float *const partials = fused ? e->first_gram.f() : nullptr;
+    if (!fused) STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
     STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
     const bool bf3 = symm_bf3_usable(feat, sgrad, C, HW);
     if (bf3) STX_TRY(e->dsym_pieces.ensure(symm_pieces_elems(C) * sizeof(unsigned short)));
     unsigned short *pieces = bf3 && C % 64 == 0 ? static_cast<unsigned short *>(e->dsym_pieces.ptr) : nullptr;
     {
         ProfScope scope(e, "gram " + name, 2.0 * C * C * (double)HW, stream);
-        STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f()));
-        STX_TRY(gram_finish_launch(stream, e->gram_partials.f(), plan, nullptr, target, e->dsym.f(),
-                                   nullptr, pieces));
+        if (!fused) STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f()));
+        STX_TRY(gram_finish_launch(stream, fused ? partials : e->gram_partials.f(), plan, nullptr, target,
+                                   e->dsym.f(), nullptr, pieces));
     }
     ProfScope scope(e, "symm " + name, 2.0 * C * C * (double)HW, stream);
-    const float *block_sumsq = e->gram_partials.f() + plan.partial_floats;
+    const float *block_sumsq = (fused ? partials : e->gram_partials.f()) + plan.partial_floats;
     if (bf3) {
         const int n_wg = symm_num_workgroups(C, HW);
         STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
@@ -1041,7 +1076,7 @@ void stx_engine_destroy(stx_engine *e) {
         for (auto &s : e->sh->styles) s.gram->release();
     }
     DevBuf *bufs[] = {&e->splitk, &e->gram_partials, &e->gram, &e->dsym, &e->dsym_pieces, &e->symm_partials,
-                      &e->upload, &e->red_scratch};
+                      &e->upload, &e->red_scratch, &e->first_gram};
     for (DevBuf *b : bufs) b->release();
     for (stx_engine::ScalarArena &a : e->arena) {
         a.scalars.release();
@@ -1308,6 +1343,8 @@ int stx_features_tile(stx_engine *e, const float *img, int img_mem, int th, int 
     Blob &in = e->blobs[e->layers[0].top_blob];
     STX_TRY(copy_in(e, in.data.ptr, img, img_mem, in.count() * sizeof(float)));
     STX_TRY(begin_timing(e));
+    e->first_gram_blob = -1;       // (no loss terms here: the first layer computes no Gram partials)
+    e->first_gram_valid = false;
     // the reference rectifies the net's last blob (style_transfer.py:426)
     const int last_blob = (int)e->blobs.size() - 1;
     std::vector<char> observed(e->blobs.size(), 0);
@@ -1521,6 +1558,15 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     STX_TRY(begin_timing(e));
     std::vector<char> observed(e->blobs.size(), 0);
     for (const Tap &tp : order) observed[tp.blob] = 1;
+    // a style tap on the first layer's blob: that layer's kernel leaves its Gram partials
+    e->first_gram_blob = -1;
+    e->first_gram_valid = false;
+    for (const Tap &tp : order) {
+        const int pl = e->blobs[tp.blob].producer;
+        if (tp.t->is_style && pl > 0 && e->layers[pl].type == STX_LAYER_CONV &&
+            e->layers[pl].bottom_blob == data_blob && e->blobs[tp.blob].channels == 64)
+            e->first_gram_blob = tp.blob;
+    }
     STX_TRY(forward(e, needed, order[0].blob, interleave ? &hook : nullptr, true, &observed));
     if (!interleave) {
         // (shallowest tap first, the order the interleaved schedule queues them in: the host adds
@@ -1948,6 +1994,8 @@ int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, co
                         const float *b, int Cout, int ksize, int relu, float *y) {
     if (!e || !x || !w || !y) return STX_ERR_ARG;
     STX_TRY(e->set_device());
+    if (conv_first_usable(Cin, Cout, ksize))      // the tile path's first-layer kernel
+        return conv_first_launch(e->stream, x, w, b, y, Cin, H, W, relu, nullptr);
     const ConvConfig cfg = hook_config(e, ksize, Cin, Cout, H, W);
     const float *packed = nullptr;
     STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 0, cfg, &packed));

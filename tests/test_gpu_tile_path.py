@@ -160,3 +160,39 @@ def test_deep_dream_term_matches_reference_vectors(golden, tag, model):
     # the term really is there: without it the loss is the plain fixture's
     plain, _ = eng.sc_grad_tile(tile, (8, 16), (0, 0), cl, sl, lw, cw, sw)
     assert plain == pytest.approx(float(g['single.loss']), rel=TIGHT) and plain != loss
+
+
+@pytest.mark.parametrize('model,th,tw', [('vgg19', 96, 200), ('vgg16_avgpool', 131, 77), ('vgg19', 256, 384)])
+def test_first_layer_kernel_with_its_own_gram_partials(model, th, tw, monkeypatch):
+    """conv_first.hip computes conv1_1 and, when the blob is a style tap, the Gram partials of its
+    own output (one partial tile per workgroup, finished by the usual gram_finish).  Against the
+    separate path -- conv_mfma's first-layer configuration + gram_partial_bf3 over the blob
+    (STX_CONV_FIRST_FUSED=0) -- the blob must agree to fp32 rounding of a 27-term dot product, loss
+    and gradient to 1e-6: same arithmetic class, different summation order.  (Both are held to the
+    oracle by every other test of this file.)"""
+    from style_transfer_amd.engine import TileEngine
+    from tests.gpu_helpers import builtin_net, require_gpu, synthetic_weights
+    require_gpu()
+    net = builtin_net(model)
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(th)
+    tile = rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)
+    cl, sl = ['conv4_2'], ['conv1_1', 'conv2_1', 'conv3_1']
+    cw, sw = {'conv4_2': 0.05}, {l: 1 / 3 for l in sl}
+    out = {}
+    for fused in ('0', '1'):
+        monkeypatch.setenv('STX_CONV_FIRST_FUSED', fused)
+        eng = TileEngine(net, 0, weights)
+        r = np.random.RandomState(3)
+        eng.set_contents_and_styles(
+            [{l: np.abs(r.standard_normal(eng.feature_shape(l, th, tw))).astype(np.float32) for l in cl}],
+            [{l: np.tril(r.standard_normal((eng.layer_info(l)[1],) * 2)).astype(np.float32) for l in sl}
+             for _ in range(2)])            # two style targets: the partials are finished twice
+        loss, grad = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        again = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        assert again[0] == loss and np.array_equal(again[1], grad)        # deterministic
+        out[fused] = (loss, grad, eng.features_tile(tile, ['conv1_1'])['conv1_1'])
+        eng.close()
+    assert np.abs(out['0'][2] - out['1'][2]).max() <= 2e-6 * np.abs(out['0'][2]).max()
+    assert out['1'][0] == pytest.approx(out['0'][0], rel=1e-6)
+    assert np.abs(out['0'][1] - out['1'][1]).max() <= 1e-5 * np.abs(out['0'][1]).max()
