@@ -6,8 +6,11 @@
 // shallowest style tap, style_transfer.py:584-590).  This kernel keeps a tile of the blob on chip
 // for that: a workgroup walks 128-pixel row segments; per segment
 //   * the 3 x 3 x 130 input patch sits in LDS (next segment's patch is in flight in registers);
-//   * wave w computes pixels 32 w .. 32 w + 31 for all 64 channels: D[64][32] = W[64][27] X[27][32]
-//     as 2 x 14 v_mfma_f32_32x32x2_f32 with the filter bank resident in registers, + bias, ReLU;
+//   * wave w computes pixels 32 w .. 32 w + 31 for all 64 channels: D[64][32] = W[64][36] X[36][32]
+//     as 2 x 18 v_mfma_f32_32x32x2_f32 with the filter bank resident in registers, + bias, ReLU --
+//     k-step (q, t) pairs input planes 2q and 2q + 1 at tap t (plane 3 is zero), the order
+//     conv_mfma_kernel's first-layer configuration adds them in: the blob is BIT-IDENTICAL to that
+//     kernel's, so nothing downstream (ReLU / pooling decisions, L-BFGS trajectories) moves;
 //   * the 64 x 128 result goes to LDS as [channel][pixel]; from there it is stored with 16-byte
 //     row segments, and -- GRAM -- read back as the bf16 MFMA's fragments (8 consecutive pixels of a
 //     channel per lane), split into three bf16 pieces and multiplied into the workgroup's running
@@ -34,7 +37,7 @@ namespace {
 constexpr int kFP = 128;             // pixels per segment
 constexpr int kFM = 64;              // output channels
 constexpr int kPW = kFP + 4;         // patch row in LDS: [x0 - 1 .. x0 + 128] + pad
-constexpr int kPatch = 9 * kPW;      // 3 channels x 3 rows
+constexpr int kPatch = 12 * kPW;     // 4 planes (the fourth stays zero) x 3 rows
 constexpr int kFLd = kFP + 4;        // row of the output tile in LDS (floats)
 constexpr int kTile = kFM * kFLd;
 constexpr int kNT = 256;
@@ -68,20 +71,16 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     const int l31 = lane & 31, half = lane >> 5;
     const size_t HW = (size_t)a.H * a.W;
 
-    // ---- the filter bank as MFMA A operands: aw[mb][s] = W[mb * 32 + l31][k = 2 s + half],
-    // k = (c, ky, kx) row-major; k >= 9 K reads as zero.  boff[s]: where k sits in the patch.
-    float aw[2][14];
-    int boff[14];
+    // ---- the filter bank as MFMA A operands.  k-step s = 9 q + t: lane half h supplies input
+    // plane c = 2 q + h at tap t = 3 ky + kx (conv_mfma_kernel's order: planes in pairs, tap by
+    // tap); planes past K are zero.  aw[mb][s] = W[mb * 32 + l31][c][t].
+    float aw[2][18];
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-        const int k = 2 * s + half;
-        const bool live = k < 9 * a.K;
-        const int kk = live ? k : 0;
-        const int c = kk / 9, ky = (kk - 9 * c) / 3, kx = kk - 9 * c - 3 * ky;
-        boff[s] = (c * 3 + ky) * kPW + kx;
+    for (int s = 0; s < 18; ++s) {
+        const int c = 2 * (s / 9) + half, tap = s % 9;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
-            aw[mb][s] = live ? a.w[(size_t)(mb * 32 + l31) * (9 * a.K) + k] : 0.f;
+            aw[mb][s] = c < a.K ? a.w[((size_t)(mb * 32 + l31) * a.K + c) * 9 + tap] : 0.f;
     }
     // (the bias in LDS: 32 registers per lane otherwise)
     if (tid < kFM) bias_l[tid] = a.bias ? a.bias[tid] : 0.f;
@@ -118,6 +117,9 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
             for (int r = 0; r < 16; ++r) g[b][r] = 0.f;
     }
 
+    // the planes past K of both patch buffers: zero (0 x garbage could be NaN)
+    for (int i = tid; i < 2 * kPatch; i += kNT) patch[i] = 0.f;
+    __syncthreads();
     int t = blockIdx.x;
     if (t < a.n_tiles) {
         patch_load(t);
@@ -136,10 +138,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-        const float *pb = patch + buf * kPatch + wave * 32 + l31;
+        // (plane 2 q + half; the fourth plane of the patch array is never written and never
+        // matters: its filter values are zero -- but it must be finite, see the clear below)
+        const float *pb = patch + buf * kPatch + half * (3 * kPW) + wave * 32 + l31;
 #pragma unroll
-        for (int s = 0; s < 14; ++s) {
-            const float b = pb[boff[s]];
+        for (int s = 0; s < 18; ++s) {
+            const int q = s / 9, ky = (s % 9) / 3, kx = s % 3;
+            const float b = pb[(2 * q * 3 + ky) * kPW + kx];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[0][s], b, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[1][s], b, acc[1], 0, 0, 0);
         }

@@ -167,9 +167,10 @@ def test_first_layer_kernel_with_its_own_gram_partials(model, th, tw, monkeypatc
     """conv_first.hip computes conv1_1 and, when the blob is a style tap, the Gram partials of its
     own output (one partial tile per workgroup, finished by the usual gram_finish).  Against the
     separate path -- conv_mfma's first-layer configuration + gram_partial_bf3 over the blob
-    (STX_CONV_FIRST_FUSED=0) -- the blob must agree to fp32 rounding of a 27-term dot product, loss
-    and gradient to 1e-6: same arithmetic class, different summation order.  (Both are held to the
-    oracle by every other test of this file.)"""
+    (STX_CONV_FIRST_FUSED=0): the blob is BIT-IDENTICAL (the same MFMA sequence: input planes in
+    pairs, tap by tap), so no ReLU / pooling decision can move; the Gram differs in summation
+    order only (fp32-class both ways): loss to 1e-6, gradient to 1e-5 of its maximum.  (Both are
+    held to the oracle by every other test of this file.)"""
     from style_transfer_amd.engine import TileEngine
     from tests.gpu_helpers import builtin_net, require_gpu, synthetic_weights
     require_gpu()
@@ -193,6 +194,6 @@ def test_first_layer_kernel_with_its_own_gram_partials(model, th, tw, monkeypatc
         assert again[0] == loss and np.array_equal(again[1], grad)        # deterministic
         out[fused] = (loss, grad, eng.features_tile(tile, ['conv1_1'])['conv1_1'])
         eng.close()
-    assert np.abs(out['0'][2] - out['1'][2]).max() <= 2e-6 * np.abs(out['0'][2]).max()
+    assert np.array_equal(out['0'][2], out['1'][2])
     assert out['1'][0] == pytest.approx(out['0'][0], rel=1e-6)
     assert np.abs(out['0'][1] - out['1'][1]).max() <= 1e-5 * np.abs(out['0'][1]).max()
