@@ -98,6 +98,43 @@ def test_run_ahead_step_loop_changes_no_bit(golden):
     assert np.array_equal(runs[0][2], runs[1][2])
 
 
+def test_callback_that_reads_the_image_gets_the_image_of_its_step(golden):
+    """--save-every under the run-ahead loop: a callback that declares (wants_image) that it will
+    read iteration n's image is served before iteration n + 1 is queued -- the picture it sees is
+    the one the blocking loop shows at that iteration, bit for bit."""
+    from argparse import Namespace
+    argv = str(golden['e2e.argv']).split()
+    net = builtin_net('vgg19')
+    weights = synthetic_weights(net, 0)
+
+    class Snap:
+        def __init__(self, declare):
+            self.pictures, self.n = {}, 0
+            if declare:
+                self.wants_image = lambda n: n in (2, 4)
+
+        def __call__(self, **kw):
+            self.n += 1
+            if self.n in (2, 4):
+                self.pictures[self.n] = kw['transfer'].current_raw.get().copy()
+
+    shots = []
+    for declare in (False, True):          # blocking loop (unknown callback), run-ahead loop
+        state = Namespace()
+        args = parse_args(state, argv, config_py=False)
+        farm = TileFarm(net, [0], weights, verbose=False)
+        st = StyleTransfer(farm, args, state)
+        snap = Snap(declare)
+        np.random.seed(args.seed)
+        st.transfer_multiscale([Image.fromarray(golden['e2e.content_u8'])],
+                               [Image.fromarray(golden['e2e.style_u8'])], callback=snap)
+        assert sorted(snap.pictures) == [2, 4]
+        shots.append(snap.pictures)
+        farm.close()
+    for n in (2, 4):
+        assert np.array_equal(shots[0][n], shots[1][n]), n
+
+
 def test_device_preprocessing_equals_host_stitching():
     """prepare_features on the GPU (cut with roll offset, stx_map_place, stx_map_roll_add) must be
     bit-identical to the host-stitched version that mirrors the reference line by line."""
