@@ -45,6 +45,7 @@ constexpr int kPL = (9 * (kFP + 2) + kNT - 1) / kNT;     // patch loads per thre
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
 
 // LDS traffic of this wave complete, then the workgroup barrier.  NOT __syncthreads(): that also
 // waits for the wave's global STORES to be acknowledged -- here a whole segment of the blob, twice
@@ -62,7 +63,13 @@ struct FirstArgs {
 
 }  // namespace
 
-template <bool GRAM>
+// STORE: how the blob leaves -- 0: 16-byte buffer stores (row length a multiple of 4, the common
+// case), 1: dword buffer stores (odd row lengths), 2: plain pointers behind bounds tests (blobs of
+// 4 GiB and more, beyond a buffer descriptor's reach).  The buffer forms issue the SAME number of
+// stores on every path (a lane outside the plane carries an out-of-range offset and is dropped by
+// the hardware): the compiler then knows how many younger memory operations stand between a patch
+// load and its use, and waits for the load, not for the stores.
+template <bool GRAM, int STORE>
 __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     // [patch 0 | patch 1 | output tile]; after the last segment the four waves' Gram tiles
     // (4 x 64 x 64 floats) take the whole array
@@ -87,13 +94,24 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
         for (int mb = 0; mb < 2; ++mb)
             aw[mb][s] = c < a.K ? a.w[((size_t)(mb * 32 + l31) * a.K + c) * 9 + tap] : 0.f;
     }
+    // the bank has landed before the segment loop starts: otherwise the compiler, which must assume
+    // these loads may still be in flight on the loop's first trip, waits for ALL memory traffic
+    // (vmcnt(0)) in front of every segment's first MFMA -- including the patch loads just issued
+#pragma unroll
+    for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(aw[0][s]), "v"(aw[1][s]));
     // (the bias in LDS: 32 registers per lane otherwise)
     if (tid < kFM) bias_l[tid] = a.bias ? a.bias[tid] : 0.f;
 
-    // ---- patch staging: element e of the 9 x 130 patch = (plane c * 3 + row r, column col)
-    float preg[kPL];
-    auto patch_load = [&](int t) {
-        const int ty = t / a.tiles_x, x0 = (t - ty * a.tiles_x) * kFP;
+    // ---- patch staging: element e of the 9 x 130 patch = (plane c * 3 + row r, column col).
+    // Buffer loads: what lies outside the picture carries an out-of-range offset and reads as zero
+    // -- no select behind the load, so nothing waits for it before the segment's matrix work (with a
+    // conditional load the compiler put `s_waitcnt vmcnt(0)` in front of the first MFMA: a full
+    // memory round trip per segment, 93 us per 1024^2 plane).
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, (int)((size_t)a.K * HW * 4), 0x00020000);
+    constexpr unsigned kOob = 0x80000000u;
+    auto patch_load = [&](int t, float (&preg)[kPL]) {
+        const int ty = t < 0 ? -4 : t / a.tiles_x, x0 = t < 0 ? 0 : (t - ty * a.tiles_x) * kFP;
 #pragma unroll
         for (int n = 0; n < kPL; ++n) {
             const int e = tid + n * kNT;
@@ -102,10 +120,11 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
             const int yy = ty - 1 + r, xx = x0 - 1 + col;
             const bool ok = e < 9 * (kFP + 2) && c < a.K && (unsigned)yy < (unsigned)a.H &&
                             (unsigned)xx < (unsigned)a.W;
-            preg[n] = ok ? a.x[(size_t)c * HW + (size_t)yy * a.W + xx] : 0.f;
+            const unsigned off = ok ? (unsigned)((c * a.H + yy) * a.W + xx) * 4u : kOob;
+            preg[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
         }
     };
-    auto patch_store = [&](int buf) {
+    auto patch_store = [&](int buf, const float (&preg)[kPL]) {
 #pragma unroll
         for (int n = 0; n < kPL; ++n) {
             const int e = tid + n * kNT;
@@ -122,29 +141,28 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
             for (int r = 0; r < 16; ++r) g[b][r] = 0.f;
     }
 
-    // the planes past K of both patch buffers: zero (0 x garbage could be NaN)
-    for (int i = tid; i < 2 * kPatch; i += kNT) patch[i] = 0.f;
-    lds_barrier();
-    int t = blockIdx.x;
-    if (t < a.n_tiles) {
-        patch_load(t);
-        patch_store(0);
-    }
-    lds_barrier();
-    int buf = 0;
-    for (; t < a.n_tiles; t += gridDim.x, buf ^= 1) {
-        const int tn = t + gridDim.x;
-        if (tn < a.n_tiles) patch_load(tn);          // in flight during this segment
+    // One segment: the patch of segment t sits in LDS buffer `buf`; `pin` holds the patch of the
+    // workgroup's next segment (loaded one segment ago), `pout` receives the one after that.  The
+    // loads are TWO segments ahead of their use so that waiting for them (the memory counter is in
+    // issue order) never means waiting for stores younger than one whole segment -- with the loads
+    // one segment ahead every segment drained its own stores before it ended (93 us per plane).
+    const int grid = gridDim.x;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y, 0, STORE == 2 ? 0 : (int)(unsigned)((size_t)kFM * HW * 4), 0x00020000);
+    constexpr unsigned kOobY = 0xfffffff0u;
+    auto segment = [&](int t, int buf, const float (&pin)[kPL], float (&pout)[kPL]) {
+        // (past the last segment: every offset out of range, the loads return zeros nobody uses --
+        // unconditional, like the stores, so that the memory counter's arithmetic is exact)
+        patch_load(t + 2 * grid < a.n_tiles ? t + 2 * grid : -1, pout);
         const int ty = t / a.tiles_x, x0 = (t - ty * a.tiles_x) * kFP;
 
-        // ---- convolution: 2 channel blocks x 14 k-steps on this wave's 32 pixels
+        // ---- convolution: 2 channel blocks x 18 k-steps on this wave's 32 pixels
         f32x16 acc[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-        // (plane 2 q + half; the fourth plane of the patch array is never written and never
-        // matters: its filter values are zero -- but it must be finite, see the clear below)
+        // (plane 2 q + half; the fourth plane of the patch array is zero and so are its filters)
         const float *pb = patch + buf * kPatch + half * (3 * kPW) + wave * 32 + l31;
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
@@ -177,14 +195,24 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
                 const int e = tid + n * kNT;
                 const int ch = e / (kFP / 4), c4 = (e - ch * (kFP / 4)) * 4;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + ch * kFLd + c4);
-                float *const dst = yrow + (size_t)ch * HW + c4;
-                if (a.vec_store && x0 + c4 + 3 < a.W) {
-                    *reinterpret_cast<f32x4 *>(dst) = v;
-                } else {
+                if (STORE == 2) {
+                    float *const dst = yrow + (size_t)ch * HW + c4;
                     if (x0 + c4 + 0 < a.W) dst[0] = v.x;
                     if (x0 + c4 + 1 < a.W) dst[1] = v.y;
                     if (x0 + c4 + 2 < a.W) dst[2] = v.z;
                     if (x0 + c4 + 3 < a.W) dst[3] = v.w;
+                    continue;
+                }
+                const unsigned base = (unsigned)(((size_t)ch * HW + (size_t)ty * a.W + x0 + c4) * 4);
+                if (STORE == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4f, v), ry,
+                                                           x0 + c4 < a.W ? base : kOobY, 0, 0);
+                } else {
+                    const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs[i]), ry,
+                                                              x0 + c4 + i < a.W ? base + 4u * i : kOobY, 0, 0);
                 }
             }
         }
@@ -206,8 +234,24 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
                 g[2] = mfma_split6(p[1], p[1], g[2]);
             }
         }
-        if (tn < a.n_tiles) patch_store(buf ^ 1);
+        if (t + grid < a.n_tiles) patch_store(buf ^ 1, pin);
         lds_barrier();      // tile reads done; the next patch is in place
+    };
+
+    // the planes past K of both patch buffers: zero (0 x garbage could be NaN)
+    for (int i = tid; i < 2 * kPatch; i += kNT) patch[i] = 0.f;
+    lds_barrier();
+    float pa[kPL], pb2[kPL];
+    const int t0 = blockIdx.x;
+    if (t0 < a.n_tiles) {
+        patch_load(t0, pa);
+        patch_store(0, pa);
+    }
+    if (t0 + grid < a.n_tiles) patch_load(t0 + grid, pa);
+    lds_barrier();
+    for (int t = t0; t < a.n_tiles; t += 2 * grid) {
+        segment(t, 0, pa, pb2);
+        if (t + grid < a.n_tiles) segment(t + grid, 1, pb2, pa);
     }
 
     if (GRAM) {
@@ -260,6 +304,10 @@ int conv_first_workgroups(int H, int W) {
 // of 64 x 64 floats, to be finished with a GramPlan {C 64, HW, splits = that count, tiles 1}.
 int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const float *bias, float *y,
                       int K, int H, int W, int relu, float *gram_partials) {
+    if (4.0 * K * (double)H * W >= 2147483648.0) {       // (tiles beyond 13 000 x 13 000: the 8192^2 limit
+        set_error("conv_first_launch: a %d x %d plane is beyond the buffer-addressing limit", H, W);   // of the
+        return STX_ERR_UNSUPPORTED;                       //  other kernels comes first)
+    }
     FirstArgs a;
     a.x = x;
     a.w = w_caffe;
@@ -274,10 +322,18 @@ int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const
     a.relu = relu;
     a.vec_store = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     const int grid = conv_first_workgroups(H, W);
-    if (gram_partials)
-        conv_first_kernel<true><<<grid, kNT, 0, s>>>(a);
-    else
-        conv_first_kernel<false><<<grid, kNT, 0, s>>>(a);
+    const int store = 4.0 * kFM * (double)H * W >= 4294967280.0 ? 2 : a.vec_store ? 0 : 1;
+#define STX_FIRST(G, S) conv_first_kernel<G, S><<<grid, kNT, 0, s>>>(a)
+    if (gram_partials) {
+        if (store == 0) STX_FIRST(true, 0);
+        else if (store == 1) STX_FIRST(true, 1);
+        else STX_FIRST(true, 2);
+    } else {
+        if (store == 0) STX_FIRST(false, 0);
+        else if (store == 1) STX_FIRST(false, 1);
+        else STX_FIRST(false, 2);
+    }
+#undef STX_FIRST
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
