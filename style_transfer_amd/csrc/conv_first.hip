@@ -6,8 +6,10 @@
 // shallowest style tap, style_transfer.py:584-590).  This kernel keeps a tile of the blob on chip
 // for that: a workgroup walks 128-pixel row segments; per segment
 //   * the 3 x 3 x 130 input patch sits in LDS (next segment's patch is in flight in registers);
-//   * wave w computes pixels 32 w .. 32 w + 31 for all 64 channels: D[64][32] = W[64][36] X[36][32]
-//     as 2 x 18 v_mfma_f32_32x32x2_f32 with the filter bank resident in registers, + bias, ReLU --
+//   * wave w computes pixels 32 w .. 32 w + 31 for all 64 channels: D[32][64] = X^T[32][36] W^T[36][64]
+//     (pixels as MFMA rows: a lane then holds four CONSECUTIVE pixels of one channel per register
+//     quad, 16-byte LDS writes and a per-lane bias) as 2 x 18 v_mfma_f32_32x32x2_f32 with the filter
+//     bank resident in registers, + bias, ReLU --
 //     k-step (q, t) pairs input planes 2q and 2q + 1 at tap t (plane 3 is zero), the order
 //     conv_mfma_kernel's first-layer configuration adds them in: the blob is BIT-IDENTICAL to that
 //     kernel's, so nothing downstream (ReLU / pooling decisions, L-BFGS trajectories) moves;
@@ -50,6 +52,7 @@ typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
 // LDS traffic of this wave complete, then the workgroup barrier.  NOT __syncthreads(): that also
 // waits for the wave's global STORES to be acknowledged -- here a whole segment of the blob, twice
 // per segment: 5.6 us per segment instead of ~2 (the first version: 93 us per 1024^2 plane).
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct FirstArgs {
@@ -75,7 +78,6 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     // (4 x 64 x 64 floats) take the whole array
     constexpr int kWork = 2 * kPatch + kTile, kRed = 4 * kFM * kFM;
     __shared__ __attribute__((aligned(16))) float lds[GRAM && kRed > kWork ? kRed : kWork];
-    __shared__ float bias_l[kFM];
     float *const patch = lds;
     float *const tile = lds + 2 * kPatch;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,9 +85,10 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     const int l31 = lane & 31, half = lane >> 5;
     const size_t HW = (size_t)a.H * a.W;
 
-    // ---- the filter bank as MFMA A operands.  k-step s = 9 q + t: lane half h supplies input
-    // plane c = 2 q + h at tap t = 3 ky + kx (conv_mfma_kernel's order: planes in pairs, tap by
-    // tap); planes past K are zero.  aw[mb][s] = W[mb * 32 + l31][c][t].
+    // ---- the filter bank as MFMA B operands (columns = channels).  k-step s = 9 q + t: lane half h
+    // supplies input plane c = 2 q + h at tap t = 3 ky + kx (conv_mfma_kernel's order: planes in
+    // pairs, tap by tap -- the same products summed in the same order, whichever operand is
+    // which); planes past K are zero.  aw[mb][s] = W[mb * 32 + l31][c][t].
     float aw[2][18];
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
@@ -99,8 +102,11 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     // (vmcnt(0)) in front of every segment's first MFMA -- including the patch loads just issued
 #pragma unroll
     for (int s = 0; s < 18; ++s) asm volatile("" ::"v"(aw[0][s]), "v"(aw[1][s]));
-    // (the bias in LDS: 32 registers per lane otherwise)
-    if (tid < kFM) bias_l[tid] = a.bias ? a.bias[tid] : 0.f;
+    // (the lane's accumulator COLUMN is channel mb * 32 + l31: one bias value per block)
+    float bias_r[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) bias_r[mb] = a.bias ? a.bias[mb * 32 + l31] : 0.f;
+    asm volatile("" ::"v"(bias_r[0]), "v"(bias_r[1]));
 
     // ---- patch staging: element e of the 9 x 130 patch = (plane c * 3 + row r, column col).
     // Buffer loads: what lies outside the picture carries an out-of-range offset and reads as zero
@@ -110,27 +116,43 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x), 0, (int)((size_t)a.K * HW * 4), 0x00020000);
     constexpr unsigned kOob = 0x80000000u;
+    // per-thread constants of its (up to) five patch elements: row - 1, column - 1 and the offset
+    // of (plane, row - 1, column - 1) relative to the segment's first pixel; an element past the
+    // patch (or of a plane past K) gets a row that is never inside the picture
+    int p_row[kPL], p_col[kPL], p_off[kPL];
+#pragma unroll
+    for (int n = 0; n < kPL; ++n) {
+        const int e = tid + n * kNT;
+        const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
+        const int c = pr / 3, r = pr - 3 * c;
+        const bool live = e < 9 * (kFP + 2) && c < a.K;
+        p_row[n] = live ? r - 1 : -(1 << 28);
+        p_col[n] = col - 1;
+        p_off[n] = (c * a.H + r - 1) * a.W + col - 1;
+    }
     auto patch_load = [&](int t, float (&preg)[kPL]) {
-        const int ty = t < 0 ? -4 : t / a.tiles_x, x0 = t < 0 ? 0 : (t - ty * a.tiles_x) * kFP;
+        // (t < 0: past the last segment -- every row outside the picture)
+        const int ty = sgpr(t < 0 ? -4 : t / a.tiles_x);
+        const int x0 = sgpr(t < 0 ? 0 : (t - ty * a.tiles_x) * kFP);
+        const int origin = sgpr(ty * a.W + x0);
 #pragma unroll
         for (int n = 0; n < kPL; ++n) {
-            const int e = tid + n * kNT;
-            const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
-            const int c = pr / 3, r = pr - 3 * c;
-            const int yy = ty - 1 + r, xx = x0 - 1 + col;
-            const bool ok = e < 9 * (kFP + 2) && c < a.K && (unsigned)yy < (unsigned)a.H &&
-                            (unsigned)xx < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)((c * a.H + yy) * a.W + xx) * 4u : kOob;
+            const bool ok = (unsigned)(ty + p_row[n]) < (unsigned)a.H && (unsigned)(x0 + p_col[n]) < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(origin + p_off[n]) * 4u : kOob;
             preg[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
         }
     };
+    int p_dst[kPL];      // where the element goes in a patch buffer (-1: not part of the patch)
+#pragma unroll
+    for (int n = 0; n < kPL; ++n) {
+        const int e = tid + n * kNT;
+        const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
+        p_dst[n] = e < 9 * (kFP + 2) ? pr * kPW + col : -1;
+    }
     auto patch_store = [&](int buf, const float (&preg)[kPL]) {
 #pragma unroll
-        for (int n = 0; n < kPL; ++n) {
-            const int e = tid + n * kNT;
-            const int pr = e / (kFP + 2), col = e - pr * (kFP + 2);
-            if (e < 9 * (kFP + 2)) patch[buf * kPatch + pr * kPW + col] = preg[n];
-        }
+        for (int n = 0; n < kPL; ++n)
+            if (p_dst[n] >= 0) patch[buf * kPatch + p_dst[n]] = preg[n];
     };
 
     f32x16 g[3];       // Gram blocks (0,0), (1,0), (1,1) of this wave's pixels
@@ -150,11 +172,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         a.y, 0, STORE == 2 ? 0 : (int)(unsigned)((size_t)kFM * HW * 4), 0x00020000);
     constexpr unsigned kOobY = 0xfffffff0u;
+    const int y_ch0 = tid >> 5, y_c4 = (tid & 31) * 4;
+    const unsigned y_voff = (unsigned)(((size_t)y_ch0 * HW + y_c4) * 4);
     auto segment = [&](int t, int buf, const float (&pin)[kPL], float (&pout)[kPL]) {
         // (past the last segment: every offset out of range, the loads return zeros nobody uses --
         // unconditional, like the stores, so that the memory counter's arithmetic is exact)
         patch_load(t + 2 * grid < a.n_tiles ? t + 2 * grid : -1, pout);
-        const int ty = t / a.tiles_x, x0 = (t - ty * a.tiles_x) * kFP;
+        const int ty = sgpr(t / a.tiles_x), x0 = sgpr((t - ty * a.tiles_x) * kFP);
 
         // ---- convolution: 2 channel blocks x 18 k-steps on this wave's 32 pixels
         f32x16 acc[2];
@@ -167,52 +191,61 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             const int q = s / 9, ky = (s % 9) / 3, kx = s % 3;
-            const float b = pb[(2 * q * 3 + ky) * kPW + kx];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[0][s], b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[1][s], b, acc[1], 0, 0, 0);
+            const float xv = pb[(2 * q * 3 + ky) * kPW + kx];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, aw[0][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, aw[1][s], acc[1], 0, 0, 0);
         }
-        // ---- bias, ReLU; pixels past the end of the row are ZERO in the tile (they take part in
-        // the Gram sums and must not: relu(bias) is not zero)
-        const int px = wave * 32 + l31;
-        const bool inside = x0 + px < a.W;
+        // ---- bias, ReLU: the lane's column is channel mb * 32 + l31, register quad j its pixels
+        // 8 j + 4 half .. + 3 of the wave's 32.  Pixels past the end of the row are ZERO in the tile
+        // (they take part in the Gram sums and must not: relu(bias) is not zero) -- only the last
+        // segment of a row can have any (a uniform branch).
+        const bool ragged = x0 + kFP > a.W;
+        const int room = a.W - x0 - wave * 32 - 4 * half;      // pixels of this lane's quads inside
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[mb][r] + bias_l[ch];
-                if (a.relu) v = fmaxf(v, 0.f);
-                v = inside ? v : 0.f;
-                tile[ch * kFLd + px] = v;
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = {acc[mb][4 * j], acc[mb][4 * j + 1], acc[mb][4 * j + 2], acc[mb][4 * j + 3]};
+                v += bias_r[mb];
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                if (ragged) {
+                    v.x = 8 * j + 0 < room ? v.x : 0.f, v.y = 8 * j + 1 < room ? v.y : 0.f;
+                    v.z = 8 * j + 2 < room ? v.z : 0.f, v.w = 8 * j + 3 < room ? v.w : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(tile + (mb * 32 + l31) * kFLd + wave * 32 + 8 * j + 4 * half) = v;
             }
         lds_barrier();      // the tile is complete (and everybody has left the previous segment's reads)
 
         // ---- the blob: 16-byte row segments out of LDS
+        // thread (row y_ch0 + 8 n of the tile, columns y_c4 .. + 3), n = 0 .. 7: one vector offset per
+        // thread, the segment's origin and the row as a scalar offset
         {
             float *const yrow = a.y + (size_t)ty * a.W + x0;
+            const unsigned origin = (unsigned)sgpr((ty * a.W + x0) * 4);
+            const unsigned vo4 = x0 + y_c4 < a.W ? y_voff : kOobY;
 #pragma unroll
             for (int n = 0; n < kFM * (kFP / 4) / kNT; ++n) {
-                const int e = tid + n * kNT;
-                const int ch = e / (kFP / 4), c4 = (e - ch * (kFP / 4)) * 4;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + ch * kFLd + c4);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (y_ch0 + 8 * n) * kFLd + y_c4);
                 if (STORE == 2) {
-                    float *const dst = yrow + (size_t)ch * HW + c4;
-                    if (x0 + c4 + 0 < a.W) dst[0] = v.x;
-                    if (x0 + c4 + 1 < a.W) dst[1] = v.y;
-                    if (x0 + c4 + 2 < a.W) dst[2] = v.z;
-                    if (x0 + c4 + 3 < a.W) dst[3] = v.w;
+                    float *const dst = yrow + (size_t)(y_ch0 + 8 * n) * HW + y_c4;
+                    if (x0 + y_c4 + 0 < a.W) dst[0] = v.x;
+                    if (x0 + y_c4 + 1 < a.W) dst[1] = v.y;
+                    if (x0 + y_c4 + 2 < a.W) dst[2] = v.z;
+                    if (x0 + y_c4 + 3 < a.W) dst[3] = v.w;
                     continue;
                 }
-                const unsigned base = (unsigned)(((size_t)ch * HW + (size_t)ty * a.W + x0 + c4) * 4);
+                const unsigned so = origin + (unsigned)sgpr((int)((unsigned)(8 * n) * (unsigned)HW * 4u));
                 if (STORE == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4f, v), ry,
-                                                           x0 + c4 < a.W ? base : kOobY, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4f, v), ry, vo4, so, 0);
                 } else {
                     const float vs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs[i]), ry,
-                                                              x0 + c4 + i < a.W ? base + 4u * i : kOobY, 0, 0);
+                                                              x0 + y_c4 + i < a.W ? y_voff + 4u * i : kOobY, so, 0);
                 }
             }
         }
