@@ -20,7 +20,7 @@
 //     pair, fp32-class accuracy), wave w taking pixels 32 w .. 32 w + 31 as two 16-pixel steps.
 // At the end the four waves' tiles are added in wave order and written as ONE partial tile per
 // workgroup, in the layout gram_finish_kernel reads (splits = workgroups, one tile).  Segments are
-// dealt out statically (workgroup b takes b, b + grid, ...): every sum has a fixed order.
+// dealt out statically (workgroup b takes a contiguous run of them): every sum has a fixed order.
 //
 // Replaces, for this shape, conv_mfma_kernel's first-layer configuration (84 us at 3.2 TB/s of
 // output on a 1024^2 tile) and gram_partial_bf3_kernel's pass over the blob (56 us, 268 MB read).
@@ -61,7 +61,7 @@ struct FirstArgs {
     const float *bias;       // [64] or null
     float *y;                // [64][H][W]
     float *gram;             // GRAM: one 64 x 64 partial tile per workgroup
-    int K, H, W, tiles_x, n_tiles, relu, vec_store;
+    int K, H, W, tiles_x, n_tiles, relu, vec_store, strided;
 };
 
 }  // namespace
@@ -73,11 +73,12 @@ struct FirstArgs {
 // the hardware): the compiler then knows how many younger memory operations stand between a patch
 // load and its use, and waits for the load, not for the stores.
 template <bool GRAM, int STORE>
-__global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
-    // [patch 0 | patch 1 | output tile]; after the last segment the four waves' Gram tiles
-    // (4 x 64 x 64 floats) take the whole array
-    constexpr int kWork = 2 * kPatch + kTile, kRed = 4 * kFM * kFM;
-    __shared__ __attribute__((aligned(16))) float lds[GRAM && kRed > kWork ? kRed : kWork];
+__global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs a) {
+    // [patch 0 | patch 1 | output tile]; after the last segment the workgroup's Gram tile
+    // (64 x 64 floats) is put together at its start
+    constexpr int kWork = 2 * kPatch + kTile;
+    static_assert(kFM * kFM <= kWork, "the Gram tile must fit the working set");
+    __shared__ __attribute__((aligned(16))) float lds[kWork];
     float *const patch = lds;
     float *const tile = lds + 2 * kPatch;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +169,13 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     // loads are TWO segments ahead of their use so that waiting for them (the memory counter is in
     // issue order) never means waiting for stores younger than one whole segment -- with the loads
     // one segment ahead every segment drained its own stores before it ended (93 us per plane).
-    const int grid = gridDim.x;
+    // Segments are dealt out in CONTIGUOUS runs (STX_FIRST_STRIDED=1, read at launch: one by one
+    // across the workgroups instead): a workgroup then writes every channel row of the blob as a run
+    // of consecutive 512-byte pieces instead of one piece here and one 256 workgroups further on.
+    const int per_wg = a.strided ? 1 : (a.n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int grid = a.strided ? (int)gridDim.x : 1;                        // distance to the next segment
+    const int t_begin = a.strided ? (int)blockIdx.x : (int)blockIdx.x * per_wg;
+    const int t_end = a.strided ? a.n_tiles : (t_begin + per_wg < a.n_tiles ? t_begin + per_wg : a.n_tiles);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         a.y, 0, STORE == 2 ? 0 : (int)(unsigned)((size_t)kFM * HW * 4), 0x00020000);
     constexpr unsigned kOobY = 0xfffffff0u;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     auto segment = [&](int t, int buf, const float (&pin)[kPL], float (&pout)[kPL]) {
         // (past the last segment: every offset out of range, the loads return zeros nobody uses --
         // unconditional, like the stores, so that the memory counter's arithmetic is exact)
-        patch_load(t + 2 * grid < a.n_tiles ? t + 2 * grid : -1, pout);
+        patch_load(t + 2 * grid < t_end ? t + 2 * grid : -1, pout);
         const int ty = sgpr(t / a.tiles_x), x0 = sgpr((t - ty * a.tiles_x) * kFP);
 
         // ---- convolution: 2 channel blocks x 18 k-steps on this wave's 32 pixels
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
                 g[2] = mfma_split6(p[1], p[1], g[2]);
             }
         }
-        if (t + grid < a.n_tiles) patch_store(buf ^ 1, pin);
+        if (t + grid < t_end) patch_store(buf ^ 1, pin);
         lds_barrier();      // tile reads done; the next patch is in place
     };
 
@@ -275,46 +282,45 @@ __global__ __launch_bounds__(kNT, 2) void conv_first_kernel(FirstArgs a) {
     for (int i = tid; i < 2 * kPatch; i += kNT) patch[i] = 0.f;
     lds_barrier();
     float pa[kPL], pb2[kPL];
-    const int t0 = blockIdx.x;
-    if (t0 < a.n_tiles) {
+    const int t0 = t_begin;
+    if (t0 < t_end) {
         patch_load(t0, pa);
         patch_store(0, pa);
     }
-    if (t0 + grid < a.n_tiles) patch_load(t0 + grid, pa);
+    if (t0 + grid < t_end) patch_load(t0 + grid, pa);
     lds_barrier();
-    for (int t = t0; t < a.n_tiles; t += 2 * grid) {
+    for (int t = t0; t < t_end; t += 2 * grid) {
         segment(t, 0, pa, pb2);
-        if (t + grid < a.n_tiles) segment(t + grid, 1, pb2, pa);
+        if (t + grid < t_end) segment(t + grid, 1, pb2, pa);
     }
 
     if (GRAM) {
-        // the four waves' tiles side by side, then ((w0 + w1) + w2) + w3 per element, as
-        // gram_partial_bf3_kernel adds them; block (0, 1) of the diagonal tile stays zero
+        // the four waves' tiles added in wave order -- ((w0 + w1) + w2) + w3 per element, as
+        // gram_partial_bf3_kernel adds them -- in four rounds through ONE 16 KB tile (all four side by
+        // side would make the kernel's LDS footprint 64 KB and cost it a workgroup per CU); block
+        // (0, 1) of the diagonal tile stays zero
         lds_barrier();
-        float *red = lds + wave * (kFM * kFM);
+        float *const red = lds;
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[row * kFM + l31] = g[0][r];
-            red[row * kFM + 32 + l31] = 0.f;
-            red[(32 + row) * kFM + l31] = g[1][r];
-            red[(32 + row) * kFM + 32 + l31] = g[2][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float *q0 = red + row * kFM + l31, *q1 = red + (32 + row) * kFM + l31;
+                    q0[0] = w == 0 ? g[0][r] : q0[0] + g[0][r];
+                    if (w == 0) q0[32] = 0.f;
+                    q1[0] = w == 0 ? g[1][r] : q1[0] + g[1][r];
+                    q1[32] = w == 0 ? g[2][r] : q1[32] + g[2][r];
+                }
+            }
+            lds_barrier();
         }
-        lds_barrier();
         float *out = a.gram + (size_t)blockIdx.x * (kFM * kFM);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int e = tid + kNT * n;
-            const float4 w0 = reinterpret_cast<const float4 *>(lds)[e];
-            const float4 w1 = reinterpret_cast<const float4 *>(lds + kFM * kFM)[e];
-            const float4 w2 = reinterpret_cast<const float4 *>(lds + 2 * kFM * kFM)[e];
-            const float4 w3 = reinterpret_cast<const float4 *>(lds + 3 * kFM * kFM)[e];
-            float4 v;
-            v.x = ((w0.x + w1.x) + w2.x) + w3.x;
-            v.y = ((w0.y + w1.y) + w2.y) + w3.y;
-            v.z = ((w0.z + w1.z) + w2.z) + w3.z;
-            v.w = ((w0.w + w1.w) + w2.w) + w3.w;
-            reinterpret_cast<float4 *>(out)[e] = v;
+            reinterpret_cast<float4 *>(out)[e] = reinterpret_cast<const float4 *>(red)[e];
         }
     }
 }
@@ -331,6 +337,12 @@ bool conv_first_usable(int K, int M, int ksize) {
 int conv_first_workgroups(int H, int W) {
     const long tiles = (long)H * ceil_div(W, kFP);
     return (int)std::min<long>(tiles, 512);
+}
+// (without the Gram tile's 48 accumulator registers three workgroups fit a CU)
+static int conv_first_plain_workgroups(int H, int W) {
+    const long tiles = (long)H * ceil_div(W, kFP);
+    const char *env = getenv("STX_FIRST_WGS");
+    return (int)std::min<long>(tiles, env ? atoi(env) : 768);
 }
 
 // y = [relu](conv(x, w) + bias); gram_partials (or null): conv_first_workgroups(H, W) partial tiles
@@ -354,7 +366,11 @@ int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const
     a.n_tiles = H * a.tiles_x;
     a.relu = relu;
     a.vec_store = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-    const int grid = conv_first_workgroups(H, W);
+    const int grid = gram_partials ? conv_first_workgroups(H, W) : conv_first_plain_workgroups(H, W);
+    {
+        const char *env = getenv("STX_FIRST_STRIDED");
+        a.strided = env && atoi(env) != 0;
+    }
     const int store = 4.0 * kFM * (double)H * W >= 4294967280.0 ? 2 : a.vec_store ? 0 : 1;
 #define STX_FIRST(G, S) conv_first_kernel<G, S><<<grid, kNT, 0, s>>>(a)
     if (gram_partials) {
