@@ -38,6 +38,10 @@
 
 namespace stx {
 
+#ifdef STX_WINO2_STAMPS   // tools/ubench/wino2_bench.hip: when does every wave of every workgroup start and end, and on which CU
+struct Wino2Stamp { unsigned long long t0, t1; unsigned hw, xcc; };
+__device__ Wino2Stamp g_wino2_stamps[8192][8];
+#endif
 #ifdef STX_WINO2_TIMING   // cycle counters for tools/ubench/wino2_bench.hip
 __device__ long long g_wino2_timing[8][8];
 __device__ unsigned long long g_wino2_sums[8];   // over ALL workgroups (wave 0): see the end of the kernel
@@ -95,6 +99,9 @@ template <int EPI, int TXW, bool BIG = false, bool MK = false>
 __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     constexpr int TYW = Geo<TXW>::TYW, PR = Geo<TXW>::PR, PC = Geo<TXW>::PC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef STX_WINO2_STAMPS
+    const unsigned long long stamp0 = wall_clock64();
+#endif
     STX_T(t_start);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,13 +120,17 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // Eight channel tiles: the 32 workgroups an XCD runs at a time take 4 channel tiles x 8
     // patches instead of 8 x 4 -- per round 8.4 MB of filters + 6.5 MB of input through the L2
     // instead of 16.8 + 3.2 (512 -> 512 channels; tools/pmc_layers.py)
-    int ptile = sgpr(Lt / m_tiles);
-    int mtile = Lt - ptile * m_tiles;
-    if (m_tiles == 8 && ((a.tiles_x * a.tiles_y) & 7) == 0) {
-        const int g = Lt >> 5, r = Lt & 31;
-        mtile = (g & 1) * 4 + (r & 3);
-        ptile = (g >> 1) * 8 + (r >> 2);
-    }
+    auto item_tiles = [&](int lt, int &pt, int &mt) __attribute__((always_inline)) {
+        pt = sgpr(lt / m_tiles);
+        mt = lt - pt * m_tiles;
+        if (m_tiles == 8 && ((a.tiles_x * a.tiles_y) & 7) == 0) {
+            const int g = lt >> 5, r = lt & 31;
+            mt = (g & 1) * 4 + (r & 3);
+            pt = (g >> 1) * 8 + (r >> 2);
+        }
+    };
+    int ptile, mtile;
+    item_tiles(Lt, ptile, mtile);
     const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
     const int c_end = sgpr(EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks);
     const int y0 = sgpr((ptile / a.tiles_x) * PR);
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     // per k-step, strict ping-pong with two barriers, a persistent variant (work items from a
     // ticket counter, first loads of the next item issued before the epilogue of the current
     // one: the ~4 us a workgroup spends outside its chunk loop are its own prologue and
-    // epilogue, not the ~2 us turnaround of a CU, tools/ubench/launch_gap.hip).
+    // epilogue, not the turnaround of a CU: 0.2-0.4 us, tools/ubench/wg_turnaround.hip).
     int cur = 0;
     int chunk = c_begin;
     [[maybe_unused]] long long t_work = 0;
@@ -744,6 +755,14 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     }
 #undef STX_PK_ADD
 #undef STX_PK_SUB
+#ifdef STX_WINO2_STAMPS
+    if (lane == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wino2_stamps[blockIdx.x][wave] = Wino2Stamp{stamp0, (unsigned long long)wall_clock64(), hw, xcc};
+    }
+#endif
 #ifdef STX_WINO2_TIMING
     if (blockIdx.x == gridDim.x - 3 && lane == 0) {     // a workgroup of the last round
         g_wino2_timing[wave][0] = t_work, g_wino2_timing[wave][2] = w_main_end - w_begin;   // 100 MHz ticks

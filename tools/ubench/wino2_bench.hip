@@ -6,7 +6,9 @@
 // spent in its compute segments, hand-over segments and barrier waits; the harness prints them.
 #include "../../style_transfer_amd/csrc/conv_wino2.hip"
 
+#include <algorithm>
 #include <cmath>
+#include <map>
 #include <cstring>
 #include <vector>
 
@@ -81,6 +83,43 @@ static void run(int K, int M, int H, int W, int epilogue) {
     const double flop = 2.0 * M * K * 9 * H * W;
     printf("K %4d M %4d %4dx%-4d epi %d: %.3f ms  %.1f TFLOP/s (direct-equivalent)  %.1f%% of MFMA time\n",
            K, M, H, W, epilogue, ms, flop / ms / 1e9, 100.0 * (flop * 16 / 36 / 157.3e12) / (ms * 1e-3));
+#ifdef STX_WINO2_STAMPS
+    if (cfg.id < 210) {      // per CU: how long a workgroup runs, and how long the CU stands empty before the next one starts
+        static stx::Wino2Stamp st[8192][8];
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(stx::g_wino2_stamps), sizeof(st));
+        const int tiles = ((H + 1) / 2) * ((W + 1) / 2);
+        (void)tiles;
+        struct Wg { unsigned long long t0, t1, last_start; };
+        std::map<unsigned, std::vector<Wg>> per_cu;
+        int n = 0;
+        for (int b = 0; b < 8192; ++b) {
+            if (st[b][0].t1 == 0) continue;
+            Wg g{~0ull, 0, 0};
+            for (int wv = 0; wv < 8; ++wv) {
+                g.t0 = std::min(g.t0, st[b][wv].t0), g.t1 = std::max(g.t1, st[b][wv].t1);
+                g.last_start = std::max(g.last_start, st[b][wv].t0);
+            }
+            per_cu[(st[b][0].xcc & 0xf) << 16 | (st[b][0].hw & 0xff00)].push_back(g);
+            ++n;
+        }
+        std::vector<double> gaps, lens, skew;
+        for (auto &kv : per_cu) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Wg &x, const Wg &y) { return x.t0 < y.t0; });
+            for (size_t i = 0; i < v.size(); ++i) {
+                lens.push_back((v[i].t1 - v[i].t0) * 0.01);
+                skew.push_back((v[i].last_start - v[i].t0) * 0.01);
+                if (i + 1 < v.size()) gaps.push_back(((double)v[i + 1].t0 - (double)v[i].t1) * 0.01);
+            }
+        }
+        auto pct = [](std::vector<double> &v, double p) { std::sort(v.begin(), v.end()); return v.empty() ? 0. : v[(size_t)(p * (v.size() - 1))]; };
+        printf("   stamps: %d workgroups on %zu CUs; workgroup first wave in -> last wave out: median %.2f us (p10 %.2f, p90 %.2f); "
+               "CU empty between two workgroups: median %.2f us (p10 %.2f, p90 %.2f, max %.2f); last wave starts %.2f us after the first\n",
+               n, per_cu.size(), pct(lens, .5), pct(lens, .1), pct(lens, .9), pct(gaps, .5), pct(gaps, .1), pct(gaps, .9), pct(gaps, 1.), pct(skew, .5));
+        static stx::Wino2Stamp zero[8192][8];
+        hipMemcpyToSymbol(HIP_SYMBOL(stx::g_wino2_stamps), zero, sizeof(zero));
+    }
+#endif
 #ifdef STX_WINO4_TIMING
     if (cfg.id >= 210) {
         long long t4[4][4];
