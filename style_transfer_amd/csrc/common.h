@@ -162,6 +162,20 @@ int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed_
 size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed_weights);
 
 int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit);
+// The same for the work items item_base .. item_base + items - 1 of a 2-D Winograd launch only (64
+// channels x one pr x pc pixel patch each, in the kernel's own item order): conv_wino2's tail split.
+int splitk_reduce_items_launch(hipStream_t s, const ConvProblem &p, const ConvConfig &cfg, int slices,
+                               int item_base, int items);
+// Work item lt of a 2-D Winograd launch -> (pixel patch, channel tile); conv_wino2.hip's order.
+__host__ __device__ inline void wino2_item_tiles(int lt, int m_tiles, int n_patches, int &pt, int &mt) {
+    pt = lt / m_tiles;
+    mt = lt - pt * m_tiles;
+    if (m_tiles == 8 && (n_patches & 7) == 0) {
+        const int g = lt >> 5, r = lt & 31;
+        mt = (g & 1) * 4 + (r & 3);
+        pt = (g >> 1) * 8 + (r >> 2);
+    }
+}
 
 // Kernel arguments shared by the Winograd kernels.
 struct WinoArgs {
@@ -183,6 +197,7 @@ struct WinoArgs {
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
     long long *clock_out = nullptr;             // ConvProblem::clock_out
+    int item_base = 0;                          // conv_wino2, K slices: first work item of the launch (tail split)
 #ifdef STX_EXPERIMENT_BF3
     int vp_rows = 0, vp_tp = 0;                 // tools/experiments/conv_bf3.hip only
 #endif
@@ -217,6 +232,12 @@ bool wino2_fuses_pool(const ConvProblem &p);
 // True if a launch of p under cfg writes p.in_codes (forward) / reads p.mask_codes (backward).
 bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
+// Tail split: a launch of n = 256 q + r work items (q >= 1) runs its last r items as r x slices K
+// slices -- one short round instead of a mostly empty full one -- and a reduce pass over those r
+// patches only.  {0, 1}: not for this problem.  Shape and epilogue only, like the K split.
+struct Wino2Tail { int items, slices; };
+Wino2Tail wino2_tail_split(const ConvConfig &cfg, const ConvProblem &p);
+int wino2_max_slices(const ConvConfig &cfg, const ConvProblem &p);
 
 // Four-wave form of the same kernel (conv_wino4.hip); config ids 210 (4 x 64 pixel patches),
 // 211 (16 x 16), 212 (8 x 32).  Shares the packed bank, the pooling rule and the K-split model.

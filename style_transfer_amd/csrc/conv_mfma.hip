@@ -486,28 +486,58 @@ struct SplitReduceArgs {
     int ksplit, M, HW, W, relu, epilogue;
 };
 
+__device__ __forceinline__ void splitk_reduce_element(const SplitReduceArgs &a, size_t n, size_t i, float s_scale,
+                                                      float c_scale) {
+    float v = a.part[i];
+    for (int k = 1; k < a.ksplit; ++k) v += a.part[(size_t)k * n + i];
+    const int m = i / a.HW;
+    if (a.epilogue == kEpiForward) {
+        if (a.bias) v += a.bias[m];
+        if (a.relu) v = fmaxf(v, 0.f);
+    } else {
+        if (a.mask) v = a.mask[i] > 0.f ? v : 0.f;
+        if (a.inj.content) {
+            const int pix = i - (size_t)m * a.HW;
+            v += c_scale * (a.inj.feat[i] -
+                            a.inj.content[content_index(a.inj.win, m, pix / a.W, pix % a.W)]);
+        }
+        if (a.inj.sgrad) v += s_scale * a.inj.sgrad[i];
+    }
+    a.y[i] = v;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
     const size_t n = (size_t)a.M * a.HW;
     float s_scale = 0.f, c_scale = 0.f;
     if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / (float)n + kEps));
     if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / (float)n + kEps));
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = a.part[i];
-        for (int k = 1; k < a.ksplit; ++k) v += a.part[(size_t)k * n + i];
-        const int m = i / a.HW;
-        if (a.epilogue == kEpiForward) {
-            if (a.bias) v += a.bias[m];
-            if (a.relu) v = fmaxf(v, 0.f);
-        } else {
-            if (a.mask) v = a.mask[i] > 0.f ? v : 0.f;
-            if (a.inj.content) {
-                const int pix = i - (size_t)m * a.HW;
-                v += c_scale * (a.inj.feat[i] -
-                                a.inj.content[content_index(a.inj.win, m, pix / a.W, pix % a.W)]);
-            }
-            if (a.inj.sgrad) v += s_scale * a.inj.sgrad[i];
-        }
-        a.y[i] = v;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        splitk_reduce_element(a, n, i, s_scale, c_scale);
+}
+
+// The same over the 64-channel x (pr x pc)-pixel patches of a range of 2-D Winograd work items
+// (conv_wino2's tail split): one thread per element (the slices of an element are read one after
+// the other, so the pass lives on the number of threads in flight: with 16 elements per thread it
+// took 60 us for 32 patches), threads along the patch's rows.
+struct ItemRange {
+    int item_base, m_tiles, tiles_x, tiles_y, pr, pc, H;
+};
+constexpr int kItemBlocks = 64;       // x 256 threads = 64 channels x 256 pixels
+
+__global__ __launch_bounds__(256) void splitk_reduce_items_kernel(SplitReduceArgs a, ItemRange r) {
+    const size_t n = (size_t)a.M * a.HW;
+    float s_scale = 0.f, c_scale = 0.f;
+    if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / (float)n + kEps));
+    if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / (float)n + kEps));
+    int pt, mt;
+    wino2_item_tiles(r.item_base + (int)(blockIdx.x / kItemBlocks), r.m_tiles, r.tiles_x * r.tiles_y, pt, mt);
+    const int y0 = (pt / r.tiles_x) * r.pr, x0 = (pt % r.tiles_x) * r.pc, m0 = mt * 64;
+    const int patch = r.pr * r.pc, total = 64 * patch;
+    for (int e = (int)(blockIdx.x % kItemBlocks) * 256 + (int)threadIdx.x; e < total; e += kItemBlocks * 256) {
+        const int mm = e / patch, rem = e - mm * patch;
+        const int yy = y0 + rem / r.pc, xx = x0 + rem % r.pc, m = m0 + mm;
+        if (m < a.M && yy < r.H && xx < a.W)
+            splitk_reduce_element(a, n, (size_t)m * a.HW + (size_t)yy * a.W + xx, s_scale, c_scale);
     }
 }
 
@@ -534,7 +564,9 @@ int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed)
 }
 
 size_t conv_splitk_floats(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
-    const int f = conv_splitk_factor(cfg, p, packed);
+    int f = conv_splitk_factor(cfg, p, packed);
+    if (packed && p.ksize == 3 && cfg.id >= 200 && cfg.id < 210)     // (the tail split's slices are whole planes too)
+        f = std::max(f, wino2_max_slices(cfg, p));
     return f > 1 ? (size_t)f * p.M * p.H * p.W : 0;
 }
 
@@ -639,7 +671,7 @@ reduce:
     return splitk_reduce_launch(s, p, ksplit);
 }
 
-int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
+static SplitReduceArgs splitk_reduce_args(const ConvProblem &p, int ksplit) {
     SplitReduceArgs r;
     r.part = p.splitk_ws;
     r.y = p.y;
@@ -652,8 +684,29 @@ int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
     r.W = p.W;
     r.relu = p.relu;
     r.epilogue = p.epilogue;
+    return r;
+}
+
+int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
+    const SplitReduceArgs r = splitk_reduce_args(p, ksplit);
     const size_t n = (size_t)p.M * p.H * p.W;
     splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, s>>>(r);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int splitk_reduce_items_launch(hipStream_t s, const ConvProblem &p, const ConvConfig &cfg, int slices,
+                               int item_base, int items) {
+    const SplitReduceArgs r = splitk_reduce_args(p, slices);
+    ItemRange range;
+    range.item_base = item_base;
+    range.m_tiles = ceil_div(p.M, 64);
+    range.tiles_x = ceil_div(p.W, cfg.pc);
+    range.tiles_y = ceil_div(p.H, cfg.pr);
+    range.pr = cfg.pr;
+    range.pc = cfg.pc;
+    range.H = p.H;
+    splitk_reduce_items_kernel<<<items * kItemBlocks, 256, 0, s>>>(r, range);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }

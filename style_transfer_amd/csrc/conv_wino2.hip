@@ -115,22 +115,14 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
     const int q8 = nb >> 3, r8 = nb & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
-    const int Lt = sgpr(EPI == kEpiPartial ? L / a.ksplit : L);
+    const int Lt = sgpr(EPI == kEpiPartial ? a.item_base + L / a.ksplit : L);
     // (channel tile slowest, so that an XCD keeps one filter slice in L2, measured no different)
     // Eight channel tiles: the 32 workgroups an XCD runs at a time take 4 channel tiles x 8
     // patches instead of 8 x 4 -- per round 8.4 MB of filters + 6.5 MB of input through the L2
-    // instead of 16.8 + 3.2 (512 -> 512 channels; tools/pmc_layers.py)
-    auto item_tiles = [&](int lt, int &pt, int &mt) __attribute__((always_inline)) {
-        pt = sgpr(lt / m_tiles);
-        mt = lt - pt * m_tiles;
-        if (m_tiles == 8 && ((a.tiles_x * a.tiles_y) & 7) == 0) {
-            const int g = lt >> 5, r = lt & 31;
-            mt = (g & 1) * 4 + (r & 3);
-            pt = (g >> 1) * 8 + (r >> 2);
-        }
-    };
+    // instead of 16.8 + 3.2 (512 -> 512 channels; tools/pmc_layers.py)  [common.h: wino2_item_tiles]
     int ptile, mtile;
-    item_tiles(Lt, ptile, mtile);
+    wino2_item_tiles(Lt, m_tiles, a.tiles_x * a.tiles_y, ptile, mtile);
+    ptile = sgpr(ptile);
     const int c_begin = sgpr(EPI == kEpiPartial ? kslice * a.n_chunks / a.ksplit : 0);
     const int c_end = sgpr(EPI == kEpiPartial ? (kslice + 1) * a.n_chunks / a.ksplit : a.n_chunks);
     const int y0 = sgpr((ptile / a.tiles_x) * PR);
@@ -822,7 +814,35 @@ int wino2_pick_geometry(int H, int W) {
 // in two: 0.167 ms where the unsplit launch takes 0.11).  The factor minimises a cost model of
 // whole rounds of 256 workgroups -- chunks x 2.05 us + 6 us each -- plus the reduce pass over
 // the slices; it depends on the shape only.
-int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
+static double wino2_round_us(int chunks) { return chunks * 2.05 + 6.0; }
+
+// (cost in model microseconds, 0 slices = not applicable)
+static Wino2Tail wino2_tail_plan(const ConvConfig &cfg, const ConvProblem &p, double *cost, bool any_epilogue = false) {
+    const Wino2Tail none{0, 1};
+    if (cfg.id < 200 || cfg.id >= 210) return none;      // (the eight-wave kernel only)
+    if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return none;
+    // the fused pooling and the ReLU nibbles belong to the unsplit epilogue
+    if (!any_epilogue && (p.pool_out || p.in_codes || p.mask_codes)) return none;
+    const char *env = getenv("STX_WINO2_TAIL");      // (=0: off; read at every call)
+    if (env && atoi(env) == 0) return none;
+    const int n_chunks = ceil_div(p.K, KC);
+    const long n = (long)ceil_div(p.M, BM) * ceil_div(p.H, cfg.pr) * ceil_div(p.W, cfg.pc);
+    const int q = (int)(n / 256), r = (int)(n % 256);
+    if (q < 1 || r == 0) return none;
+    const int f = std::min({8, 256 / r, n_chunks / 4});
+    if (f < 2) return none;
+    const double patch_mb = 4e-6 * BM * cfg.pr * cfg.pc;
+    // whole rounds + the short round (its workgroups all start into the same burst of first loads:
+    // 12 us beside their chunks, measured) + the reduce pass over r patches + two more launches
+    // behind a drained GPU (7 us each, measured)
+    *cost = q * wino2_round_us(n_chunks) + (ceil_div(n_chunks, f) * 2.05 + 12.0) +
+            (f + 1) * r * patch_mb / 3.0 + 5.0 + 2 * 7.0;
+    return Wino2Tail{r, f};
+}
+
+// Uniform K split, or none: {factor, model cost}
+static int wino2_uniform_plan(const ConvConfig &cfg, const ConvProblem &p, double *cost) {
+    *cost = 0;
     if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return 1;
     const int n_chunks = ceil_div(p.K, KC);
     const long n = (long)ceil_div(p.M, BM) * ceil_div(p.H, cfg.pr) * ceil_div(p.W, cfg.pc);
@@ -831,14 +851,36 @@ int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
     int best = 1;
     for (int f = 1; f <= 8 && n_chunks / f >= 4; ++f) {
         const double rounds = (double)ceil_div((int)std::min<long>(n * f, 1 << 30), 256);
-        double cost = rounds * ((double)n_chunks / f * 2.05 + 6.0);
-        if (f > 1) cost += (f + 1) * out_mb / 3.0 + 5.0;      // reduce pass at ~3 TB/s + its launch
-        if (f == 1 || cost < best_cost) {
-            best_cost = cost;
+        double c = rounds * ((double)n_chunks / f * 2.05 + 6.0);
+        if (f > 1) c += (f + 1) * out_mb / 3.0 + 5.0;      // reduce pass at ~3 TB/s + its launch
+        if (f == 1 || c < best_cost) {
+            best_cost = c;
             best = f;
         }
     }
+    *cost = best_cost;
     return best;
+}
+
+Wino2Tail wino2_tail_split(const ConvConfig &cfg, const ConvProblem &p) {
+    double tail_cost = 0, uniform_cost = 0;
+    const Wino2Tail t = wino2_tail_plan(cfg, p, &tail_cost);
+    if (t.items == 0) return t;
+    wino2_uniform_plan(cfg, p, &uniform_cost);
+    return tail_cost < uniform_cost ? t : Wino2Tail{0, 1};
+}
+
+int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
+    if (wino2_tail_split(cfg, p).items) return 1;      // (the launch slices its last items itself)
+    double c;
+    return wino2_uniform_plan(cfg, p, &c);
+}
+
+// The most plane-sized slices either split of this shape can ask for (the scratch buffer is sized
+// before the caller has attached pooling or ReLU-nibble outputs to the problem).
+int wino2_max_slices(const ConvConfig &cfg, const ConvProblem &p) {
+    double c;
+    return std::max(wino2_uniform_plan(cfg, p, &c), wino2_tail_plan(cfg, p, &c, true).slices);
 }
 
 size_t wino2_packed_floats(int K, int M) {
@@ -931,6 +973,9 @@ static int wino2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
     return STX_OK;
 }
 
+static int wino2_launch_tail(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, const WinoArgs &whole,
+                             int epi, const Wino2Tail &tail);
+
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
     if (cfg.id >= 210) return wino4_launch(s, cfg, p, ksplit);
     WinoArgs a;
@@ -991,6 +1036,11 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         a.skip_y = p.skip_y && p.pool_codes != nullptr;
     }
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
+    if (!split && !big && !mk && !a.pool_out && ksplit == 1) {
+        const Wino2Tail tail = wino2_tail_split(cfg, p);
+        if (tail.items && p.splitk_ws && p.splitk_ws_floats >= (size_t)tail.slices * p.M * p.H * p.W)
+            return wino2_launch_tail(s, cfg, p, a, epi, tail);
+    }
 #define STX_W2_CASE(E)                                                                            \
     case E:                                                                                       \
         if (big && E != kEpiPartial)                                                              \
@@ -1017,6 +1067,40 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     }
 #undef STX_W2_CASE
     return split ? splitk_reduce_launch(s, p, ksplit) : STX_OK;
+}
+
+// The tail split of a launch (common.h: wino2_tail_split): whole rounds as they are, then the
+// remaining items as K slices in ONE short round, then the slices of those items' patches added
+// up with the epilogue the unsplit kernel would have applied.
+static int wino2_launch_tail(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, const WinoArgs &whole,
+                             int epi, const Wino2Tail &tail) {
+    const int n_items = whole.m_tiles * whole.tiles_x * whole.tiles_y;
+    const int n_full = n_items - tail.items;
+    WinoArgs part = whole;
+    part.ksplit = tail.slices;
+    part.item_base = n_full;
+    part.y = p.splitk_ws;
+    part.clock_out = nullptr;
+#define STX_W2_TAIL(E)                                                                            \
+    case E:                                                                                       \
+        STX_TRY(cfg.id == 201   ? (wino2_launch_epi<E, 8>(s, whole, n_full))                      \
+                : cfg.id == 202 ? (wino2_launch_epi<E, 16>(s, whole, n_full))                     \
+                                : (wino2_launch_epi<E, 32>(s, whole, n_full)));                   \
+        break;
+    switch (epi) {
+        STX_W2_TAIL(kEpiForward)
+        STX_W2_TAIL(kEpiDgrad)
+        STX_W2_TAIL(kEpiDgradInject)
+        default:
+            set_error("wino2_launch: no tail split for epilogue %d", epi);
+            return STX_ERR_UNSUPPORTED;
+    }
+#undef STX_W2_TAIL
+    const int n_part = tail.items * tail.slices;
+    STX_TRY(cfg.id == 201   ? (wino2_launch_epi<kEpiPartial, 8>(s, part, n_part))
+            : cfg.id == 202 ? (wino2_launch_epi<kEpiPartial, 16>(s, part, n_part))
+                            : (wino2_launch_epi<kEpiPartial, 32>(s, part, n_part)));
+    return splitk_reduce_items_launch(s, p, cfg, tail.slices, n_full, tail.items);
 }
 
 }  // namespace stx

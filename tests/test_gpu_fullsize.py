@@ -104,7 +104,9 @@ def test_sc_grad_tile_vgg16_avgpool_at_1024():
 # conv4_2, conv5_1 (K split on), and the two odd-plane relatives of a 724-pixel tile
 REAL_CONV_SHAPES = [(64, 64, 1024, 1024), (128, 128, 512, 512), (256, 256, 256, 256),
                     (512, 512, 128, 128), (512, 512, 64, 64), (128, 128, 362, 362),
-                    (256, 512, 91, 91)]
+                    (256, 512, 91, 91),
+                    # workgroup counts of 256 q + r: the last r work items run as K slices (tail split)
+                    (512, 512, 91, 91), (256, 256, 181, 181)]
 
 
 @pytest.mark.parametrize('cin,cout,h,w', REAL_CONV_SHAPES)
@@ -128,6 +130,37 @@ def test_conv_at_real_layer_shapes(cin, cout, h, w):
     ref = L.conv_backward_data(dy, wt) * (x > 0)
     assert max_rel(gx.get(), ref) < 2e-5
     for a in (dx_, dw, db, y, ddy, gx):
+        a.free()
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(512, 512, 91, 91), (256, 256, 181, 181), (256, 512, 91, 91)])
+def test_tail_split_changes_the_summation_order_only(cin, cout, h, w, monkeypatch):
+    """Launches of 256 q + r work items run their last r items as K slices (conv_wino2.hip: tail split).
+    With it and without it (STX_WINO2_TAIL=0, read at every call) the layer must agree to the kernel
+    tolerance -- and must NOT agree bit for bit on these shapes, or the path under test did not run."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(cin + h)
+    x = np.maximum(rng.standard_normal((cin, h, w)), 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2 / (9 * cin))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    dy = rng.standard_normal((cout, h, w)).astype(np.float32)
+    dx_, dw, db, ddy = eng.to_device(x), eng.to_device(wt), eng.to_device(b), eng.to_device(dy)
+    y, gx = eng.empty((cout, h, w)), eng.empty((cin, h, w))
+
+    def both():
+        lib.call('stx_op_conv_forward', eng.handle, dx_.ptr, cin, h, w, dw.ptr, db.ptr, cout, 3, 1, y.ptr)
+        lib.call('stx_op_conv_backward_data', eng.handle, ddy.ptr, cout, h, w, dw.ptr, cin, 3, dx_.ptr, gx.ptr)
+        return y.get().copy(), gx.get().copy()
+
+    monkeypatch.setenv('STX_WINO2_TAIL', '0')
+    y0, g0 = both()
+    monkeypatch.delenv('STX_WINO2_TAIL')
+    y1, g1 = both()
+    y2, g2 = both()
+    assert np.array_equal(y1, y2) and np.array_equal(g1, g2)            # (deterministic)
+    assert max_rel(y1, y0) < 2e-5 and max_rel(g1, g0) < 2e-5
+    assert not np.array_equal(y1, y0)                                     # forward: 288 / 552 / 288 work items
+    for a in (dx_, dw, db, ddy, y, gx):
         a.free()
 
 
