@@ -117,6 +117,10 @@ struct ConvProblem {
     // them ignore them (conv_uses_relu_codes).
     unsigned char *in_codes = nullptr;
     const unsigned char *mask_codes = nullptr;
+    // the caller attaches ReLU nibbles to this launch wherever the kernel takes them (it does not under
+    // STX_WINO_BIG=1, for one): launches that want them keep out of the tail split either way, so
+    // that the schedule -- and with it the rounding -- does not depend on whether they were taken
+    bool wants_codes = false;
     // kEpiForward with a fused pooling that also writes window codes: nobody will read y itself
     // (the pooled blob feeds the next layer, the backward pooling runs from the codes) -- skip
     // its stores.  Only honoured by the kernel that fuses (wino2_launch); ignored otherwise.

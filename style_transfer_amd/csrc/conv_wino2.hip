@@ -822,7 +822,7 @@ static Wino2Tail wino2_tail_plan(const ConvConfig &cfg, const ConvProblem &p, do
     if (cfg.id < 200 || cfg.id >= 210) return none;      // (the eight-wave kernel only)
     if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return none;
     // the fused pooling and the ReLU nibbles belong to the unsplit epilogue
-    if (!any_epilogue && (p.pool_out || p.in_codes || p.mask_codes)) return none;
+    if (!any_epilogue && (p.pool_out || p.wants_codes || p.in_codes || p.mask_codes)) return none;
     const char *env = getenv("STX_WINO2_TAIL");      // (=0: off; read at every call)
     if (env && atoi(env) == 0) return none;
     const int n_chunks = ceil_div(p.K, KC);
@@ -832,11 +832,11 @@ static Wino2Tail wino2_tail_plan(const ConvConfig &cfg, const ConvProblem &p, do
     const int f = std::min({8, 256 / r, n_chunks / 4});
     if (f < 2) return none;
     const double patch_mb = 4e-6 * BM * cfg.pr * cfg.pc;
-    // whole rounds + the short round (its workgroups all start into the same burst of first loads:
-    // 12 us beside their chunks, measured) + the reduce pass over r patches + two more launches
-    // behind a drained GPU (7 us each, measured)
-    *cost = q * wino2_round_us(n_chunks) + (ceil_div(n_chunks, f) * 2.05 + 12.0) +
-            (f + 1) * r * patch_mb / 3.0 + 5.0 + 2 * 7.0;
+    // whole rounds + the short round + the reduce pass over r patches + two more launches behind a
+    // drained GPU: 3 us each (fitted to the layers of a 724-pixel tile: 175 / 178 / 106 / 98 us measured
+    // where this gives 176 / 179 / 103 / 101)
+    *cost = q * wino2_round_us(n_chunks) + wino2_round_us(ceil_div(n_chunks, f)) +
+            (f + 1) * r * patch_mb / 3.0 + 5.0 + 2 * 3.0;
     return Wino2Tail{r, f};
 }
 
@@ -1017,7 +1017,11 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     // (planes that large never need a K split; the slices' kernel has no BIG form)
     const bool split = ksplit > 1 && p.splitk_ws && !huge &&
                        p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
-    const bool big = huge || (force_big && atoi(force_big) == 1 && !split);
+    // the tail split (below) likewise: its slices run the same kernel
+    const Wino2Tail tail = !split && !huge && ksplit == 1 ? wino2_tail_split(cfg, p) : Wino2Tail{0, 1};
+    const bool tail_ok = tail.items && p.splitk_ws &&
+                         p.splitk_ws_floats >= (size_t)tail.slices * p.M * p.H * p.W;
+    const bool big = huge || (force_big && atoi(force_big) == 1 && !split && !tail_ok);
     a.x_bytes = big ? 0 : (int)xb;
     // ReLU sign nibbles (see ConvProblem): written by the plain forward kernel, read by the plain
     // backward kernels; K slices and the BIG variants keep the fp32 mask
@@ -1036,11 +1040,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
         a.skip_y = p.skip_y && p.pool_codes != nullptr;
     }
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
-    if (!split && !big && !mk && !a.pool_out && ksplit == 1) {
-        const Wino2Tail tail = wino2_tail_split(cfg, p);
-        if (tail.items && p.splitk_ws && p.splitk_ws_floats >= (size_t)tail.slices * p.M * p.H * p.W)
-            return wino2_launch_tail(s, cfg, p, a, epi, tail);
-    }
+    if (tail_ok && !big && !mk && !a.pool_out) return wino2_launch_tail(s, cfg, p, a, epi, tail);
 #define STX_W2_CASE(E)                                                                            \
     case E:                                                                                       \
         if (big && E != kEpiPartial)                                                              \

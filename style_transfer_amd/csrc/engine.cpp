@@ -81,6 +81,7 @@ struct Blob {
     bool codes_valid = false; // forward pass that produced `data` if its kernel can
     DevBuf relu_codes;        // rectified blobs: sign nibbles per 2x2 window (ConvProblem::in_codes),
     bool relu_codes_valid = false;   // written by the forward pass of the convolution that reads the blob
+    bool relu_codes_wanted = false;  // ... or would have been, had its kernel taken them (ConvProblem::wants_codes)
     size_t count() const { return (size_t)channels * h * w; }
 };
 
@@ -527,6 +528,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         // partials of the blob when it is a style tap of this call
         if (pooled) *pooled = false;
         b.relu_codes_valid = false;
+        b.relu_codes_wanted = false;
         float *gram = nullptr;
         if (L.top_blob == e->first_gram_blob) {
             const int parts = conv_first_workgroups(b.h, b.w);
@@ -542,6 +544,8 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         e->flop_issued += direct;
         return conv_first_launch(e->stream, p.x, cp.w.f(), cp.b.f(), p.y, cp.cin, b.h, b.w, p.relu, gram);
     }
+    b.relu_codes_wanted = relu_codes && b.relu && b.channels <= 128;      // (see below)
+    p.wants_codes = b.relu_codes_wanted;
     ConvConfig cfg;
     STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
     const float *packed = nullptr;
@@ -554,7 +558,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     // the forward pass 10 / 16 us; from 256 channels on the backward pass is matrix-bound, gains
     // 0-7 us and the forward pass pays 5-10: measured, profiles/r03_relu_codes_ab.txt)
     b.relu_codes_valid = false;
-    if (relu_codes && b.relu && b.channels <= 128) {
+    if (b.relu_codes_wanted) {
         const size_t bytes = (size_t)b.channels * ((b.h + 1) / 2) * ((b.w + 1) / 2);
         STX_TRY(b.relu_codes.ensure(bytes));
         p.in_codes = static_cast<unsigned char *>(b.relu_codes.ptr);
@@ -597,6 +601,7 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     p.mask = b.relu ? b.data.f() : nullptr;
     // (kernels that cannot read the nibbles use the fp32 blob: conv_uses_relu_codes)
     p.mask_codes = b.relu && b.relu_codes_valid ? static_cast<const unsigned char *>(b.relu_codes.ptr) : nullptr;
+    p.wants_codes = b.relu && b.relu_codes_wanted;
     p.K = cp.cout;
     p.M = cp.cin;
     p.H = b.h;
