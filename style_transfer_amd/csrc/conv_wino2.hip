@@ -862,13 +862,15 @@ static int wino2_uniform_plan(const ConvConfig &cfg, const ConvProblem &p, doubl
     return best;
 }
 
-Wino2Tail wino2_tail_split(const ConvConfig &cfg, const ConvProblem &p) {
+static Wino2Tail wino2_tail_choice(const ConvConfig &cfg, const ConvProblem &p, bool any_epilogue) {
     double tail_cost = 0, uniform_cost = 0;
-    const Wino2Tail t = wino2_tail_plan(cfg, p, &tail_cost);
+    const Wino2Tail t = wino2_tail_plan(cfg, p, &tail_cost, any_epilogue);
     if (t.items == 0) return t;
     wino2_uniform_plan(cfg, p, &uniform_cost);
     return tail_cost < uniform_cost ? t : Wino2Tail{0, 1};
 }
+
+Wino2Tail wino2_tail_split(const ConvConfig &cfg, const ConvProblem &p) { return wino2_tail_choice(cfg, p, false); }
 
 int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
     if (wino2_tail_split(cfg, p).items) return 1;      // (the launch slices its last items itself)
@@ -880,7 +882,7 @@ int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
 // before the caller has attached pooling or ReLU-nibble outputs to the problem).
 int wino2_max_slices(const ConvConfig &cfg, const ConvProblem &p) {
     double c;
-    return std::max(wino2_uniform_plan(cfg, p, &c), wino2_tail_plan(cfg, p, &c, true).slices);
+    return std::max(wino2_uniform_plan(cfg, p, &c), wino2_tail_choice(cfg, p, true).slices);
 }
 
 size_t wino2_packed_floats(int K, int M) {
