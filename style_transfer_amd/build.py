@@ -24,6 +24,7 @@ SOURCES = {
     'conv_wino2.hip': [],
     'conv_wino4.hip': [],
     'conv_first.hip': [],
+    'conv_h2.hip': [],
     'gram.hip': [],
     'symm.hip': [],
     'pool.hip': [],

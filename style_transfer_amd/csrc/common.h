@@ -134,6 +134,11 @@ struct ConvProblem {
     // {core-clock cycles, 100 MHz ticks} spent in its chunk loop here -- the shader clock the part
     // sustains INSIDE the kernel that does 80 % of the work (null: nothing is read or stored)
     long long *clock_out = nullptr;
+    // conv_h2.hip (fp16 two-piece split): max |x| of the input planes as kAmaxSlots words of float
+    // bits (the largest one counts), left by the kernel that wrote them or by absmax_launch; y_amax
+    // (optional, zeroed by the caller): where this launch leaves max |y| of its own output
+    const unsigned *x_amax = nullptr;
+    unsigned *y_amax = nullptr;
 #ifdef STX_EXPERIMENT_BF3
     const void *x_split = nullptr;   // tools/experiments/conv_bf3.hip only
 #endif
@@ -202,6 +207,8 @@ struct WinoArgs {
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
     long long *clock_out = nullptr;             // ConvProblem::clock_out
     int item_base = 0;                          // conv_wino2, K slices: first work item of the launch (tail split)
+    const unsigned *x_amax = nullptr;           // conv_h2: ConvProblem::x_amax / y_amax
+    unsigned *y_amax = nullptr;
 #ifdef STX_EXPERIMENT_BF3
     int vp_rows = 0, vp_tp = 0;                 // tools/experiments/conv_bf3.hip only
 #endif
@@ -242,6 +249,21 @@ int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 struct Wino2Tail { int items, slices; };
 Wino2Tail wino2_tail_split(const ConvConfig &cfg, const ConvProblem &p);
 int wino2_max_slices(const ConvConfig &cfg, const ConvProblem &p);
+
+// 1-D Winograd F(2,3) on the fp16 matrix cores with two-piece operands (conv_h2.hip): fp32-class
+// accuracy at 0.28 of the fp32 2-D form's matrix time.  Config ids 300 (64 channels x 8 x 32 pixels per
+// workgroup) and 301 (128 channels); both read the same packed bank.
+constexpr int kAmaxSlots = 16;
+ConvConfig h2_config(int mb);
+ConvConfig h2_pick_config(const ConvProblem &p);    // the cheaper tiling by the round model (shape only)
+bool h2_usable(const ConvProblem &p);       // what the kernel takes (shape, epilogue, addressing)
+size_t h2_packed_floats(int K, int M);
+int h2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed);
+int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+int h2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
+bool h2_fuses_pool(const ConvProblem &p);
+// slots[0 .. kAmaxSlots) = 0, then max |x| as float bits into them (the largest slot counts)
+int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots);
 
 // Four-wave form of the same kernel (conv_wino4.hip); config ids 210 (4 x 64 pixel patches),
 // 211 (16 x 16), 212 (8 x 32).  Shares the packed bank, the pooling rule and the K-split model.

@@ -1,0 +1,837 @@
+// 3x3 convolution on the fp16 matrix cores at fp32 accuracy: 1-D Winograd F(2,3) along x with both
+// operands split into two fp16 pieces (three products per operand pair).
+//
+// Same job and interface as conv_wino2_kernel (forward + bias + ReLU + fused 2x2 pooling with window
+// codes, backward-to-data + ReLU mask + loss-gradient terms, split-K partials; Caffe's Convolution
+// layer as the reference drives it at style_transfer.py:566,606-610), for layers with a multiple of
+// 16 input channels.  For a pair of neighbouring outputs (x = 2t, 2t+1) of one row and the three taps
+// g0, g1, g2 of kernel row ky:
+//     d0..d3 = in[2t-1 .. 2t+2]          (row y + ky - 1)
+//     V = [d0-d2, d1+d2, d2-d1, d1-d3]   U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
+//     M[xi] = sum over input channels and ky of U[ky][xi] * V[ky][xi]
+//     out[2t] = M0 + M1 + M2             out[2t+1] = M1 - M2 - M3
+// V and U are formed in fp32 exactly as an fp32 Winograd kernel forms them.  Each is then scaled by a
+// power of two and written as hi + lo, hi = fp16(s a), lo = fp16(s a - hi) (round to nearest even, the
+// residual is exact): 2 x 11 significand bits.  A product is hi hi + hi lo + lo hi -- three
+// v_mfma_f32_32x32x16_f16, every fp16 x fp16 product exact in the fp32 accumulator; lo lo, 2^-22 of the
+// product, is dropped.  tools/f16x2_numerics.py: 2e-7 .. 6e-7 of max against float64, the same as the
+// fp32 2-D Winograd kernel on the same data.  Matrix time per output and channel pair: 3 (ky) x 4/2
+// (xi per pixel) x 3 products of 1/512 cycle = 18/512 against 4 x 1/32 for the fp32 2-D Winograd form:
+// 0.28 of its matrix time, and -- unlike fp32 MFMAs, which run at and on the vector rate -- fp16 MFMAs
+// leave the vector pipe to the transform and the split.
+//
+// Scales.  No fp16 value can overflow, by construction: the kernel that wrote the input blob left
+// max |x| behind (sixteen slots of float bits, combined with atomicMax: `x_amax`), and this kernel
+// scales its input by the power of two that puts that maximum into [2^13, 2^14) -- |V| < 2^15 < 65504.
+// The filter bank is scaled the same way when it is packed (its exponent sits behind the bank).  What
+// is small against the maximum loses relative precision only below 2^-17 of it.  The epilogue undoes
+// both scales (an exact multiplication) and leaves max |y| of its own output for the next layer.
+//
+// Work split.  A workgroup of eight waves computes 64 MB channels x (8 rows x 32 columns) = 128
+// x-tiles.  Wave (xi, h) owns transform component xi of MB 32-channel blocks for all four pixel blocks:
+// 4 MB accumulators of one 32 x 32 MFMA block.  Its A operand (the U pieces of its component and
+// channel blocks) is nobody else's, so it comes straight from global memory into registers, as ready
+// fragments (1 KB per piece and step), one chunk ahead.  The B operand (V pieces, shared by all channel
+// blocks) goes through LDS: [xi][piece][row][tile][16 channels], 40 KB, double buffered, one barrier
+// per chunk of 16 channels; a staging thread loads the four inputs of one tile for 4 channels (four
+// 16-byte loads), transforms, splits and writes eight 8-byte pieces.  Pixel block (m, s) holds rows
+// 4m + s and 4m + 2 + s of the patch, so that a lane's outputs in blocks (m, 0) and (m, 1) are the two
+// rows of one 2x2 pooling window.
+//
+// Epilogue.  The four components of an output pair live in four waves: the accumulators of one
+// 32-channel block per wave go through LDS (128 KB per pass, MB passes); wave (hh, m, rq pair) then
+// finishes eight channels of four rows: a 2 x 2 window per lane and channel, exactly the shape
+// conv_wino2's epilogue works on.
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+#ifndef STX_H2_SKIP
+#define STX_H2_SKIP 0   // timing experiments (tools/ubench/h2conv_bench.hip): 1 no staging, 2 no filter
+#endif                 // loads, 4 no patch loads in the main loop.  Wrong results when non-zero.
+
+namespace stx {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned int))));
+
+constexpr int KC = 16;                      // input channels per chunk = one MFMA k-step
+constexpr int NT = 512;
+constexpr int PR = 8, PC = 32, TX = PC / 2; // pixel patch; x-tiles per patch row
+constexpr int XR = PR + 2;                  // input rows of the patch
+constexpr int RT = XR * TX;                 // (row, tile) positions of V: 160
+constexpr int V_PIECE = RT * 32;            // bytes of one [rt][16 ch] fp16 array
+constexpr int V_BYTES = 4 * 2 * V_PIECE;    // [xi][piece]: 40 KB
+constexpr int FRAG = 1024;                  // one operand fragment: 64 lanes x 8 fp16
+constexpr int U_KY = 4 * 2 * FRAG;          // [xi][piece] of one (channel block, chunk, ky): 8 KB
+constexpr int U_BLK = 3 * U_KY;             // one (channel block, chunk): 24 KB
+constexpr int EX_BYTES = 4 * 2 * 4 * 4 * 64 * 16;   // epilogue exchange: 128 KB
+constexpr size_t kLdsBytes = EX_BYTES > 2 * V_BYTES ? EX_BYTES : 2 * V_BYTES;
+constexpr int kHeaderFloats = 64;           // behind the bank: [0] max |U| (float bits), [1] the scale's exponent
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// a loop the compiler cannot decline to unroll (the bodies index register arrays)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// power of two s (as an exponent) with amax * 2^s in [2^13, 2^14); amax given as float bits
+__host__ __device__ inline int h2_scale_exp(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);      // biased exponent of the maximum
+    int s = 13 - (e - 127);
+    return s < -126 ? -126 : s > 127 ? 127 : s;          // (zero blobs: any scale does)
+}
+__device__ __forceinline__ float pow2f(int e) {          // 2^e, e clamped to the normal range
+    const int b = e + 127;
+    return __builtin_bit_cast(float, (unsigned)(b < 1 ? 1 : b > 254 ? 254 : b) << 23);
+}
+
+}  // namespace
+
+#ifdef STX_H2_TIMING   // cycle counters for tools/ubench/h2conv_bench.hip
+__device__ long long g_h2_timing[8][8];
+#endif
+
+template <int EPI, int MB>
+__global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+#ifdef STX_H2_TIMING
+    const long long t_start = clock64(), w_start = wall_clock64();
+#endif
+    constexpr int BM = 64 * MB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = sgpr(tid >> 6);
+    const int xi = wave & 3, wh = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // XCD-aware work order, see conv_wino2.hip
+    const int m_tiles = a.m_tiles;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot_x = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_x;
+    const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
+    const int Lt = sgpr(EPI == kEpiPartial ? a.item_base + L / a.ksplit : L);
+    int ptile, mtile;
+    wino2_item_tiles(Lt, m_tiles, a.tiles_x * a.tiles_y, ptile, mtile);
+    ptile = sgpr(ptile);
+    mtile = sgpr(mtile);
+    // (K slices are whole pairs of chunks: the chunk loop below runs two per trip)
+    const int c_begin = sgpr(EPI == kEpiPartial ? 2 * (kslice * (a.n_chunks >> 1) / a.ksplit) : 0);
+    const int c_end = sgpr(EPI == kEpiPartial ? 2 * ((kslice + 1) * (a.n_chunks >> 1) / a.ksplit) : a.n_chunks);
+    const int y0 = sgpr((ptile / a.tiles_x) * PR);
+    const int x0 = sgpr((ptile % a.tiles_x) * PC);
+    const int m0 = mtile * BM;
+    const int HW = a.H * a.W;
+    const unsigned HW4 = (unsigned)HW * 4u;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // ---- scales: the input's from the maximum its producer left, the bank's from its header
+    unsigned amax_bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax_bits = max(amax_bits, a.x_amax[i]);
+    const int es = sgpr(h2_scale_exp(amax_bits));
+    const int ew = sgpr(reinterpret_cast<const int *>(a.w)[(a.w_bytes >> 2) + 1]);
+    const float sv = pow2f(es);
+    const float out_scale = pow2f(-es - ew);
+
+    // ---- staging role.  A unit = position rt of the V array x four channels (quad): 640 units per
+    // chunk; every thread has unit tid, the threads of waves 0 and 1 also unit 512 + tid.
+    const int n_units = wave < 2 ? 2 : 1;                 // wave-uniform
+    const bool edge = x0 == 0 || x0 + PC + 2 > a.W;       // workgroup-uniform
+    unsigned xvoff[2], v_dst[2];
+    bool left[2], ok2[2], ok3[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int u = tid + n * NT;
+        const int quad = u & 3, rt = u >> 2;
+        const int st_r = rt / TX, st_t = rt % TX;
+        const int st_y = y0 - 1 + st_r, st_x = x0 + 2 * st_t - 1;
+        left[n] = st_x < 0;                                // x = -1: loaded from x = 0 and shifted
+        ok2[n] = st_x + 2 < a.W, ok3[n] = st_x + 3 < a.W;
+        xvoff[n] = kOob;
+        if (rt < RT && (unsigned)st_y < (unsigned)a.H && st_x + 1 < a.W)
+            xvoff[n] = (unsigned)(quad * 4 * HW + st_y * a.W + (left[n] ? 0 : st_x)) * 4u;
+        // the two 16-byte halves of a position swap places on tiles 8..15: conflict-free ds_read_b128
+        v_dst[n] = (unsigned)(rt * 32 + ((quad * 8) ^ ((st_t & 8) << 1)));
+    }
+
+    f32x4 xr[2][4];
+    auto x_load = [&](int n, int chunk) __attribute__((always_inline)) {
+        const unsigned xs = (unsigned)sgpr(chunk * KC) * HW4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xr[n][i] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[n], xs + (unsigned)i * HW4, 0));
+    };
+    // One piece of the staging work of unit n: component c of channel pair pr (7 vector
+    // instructions), plus -- behind the second pair -- the two 8-byte writes of the component.
+    unsigned pkh[2], pkl[2];
+    auto piece = [&](int n, int c, int pr, char *vbuf, bool fix) __attribute__((always_inline)) {
+        if (c == 0 && pr == 0 && fix) {
+            asm volatile("");      // (a scalar branch: workgroups on the left / right border only)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 d = xr[n][i];
+                f32x4 e;
+                e.x = left[n] ? 0.f : d.x;
+                e.y = left[n] ? d.x : d.y;
+                e.z = left[n] ? d.y : d.z;
+                e.w = left[n] ? d.z : d.w;
+                e.z = ok2[n] ? e.z : 0.f;
+                e.w = ok3[n] ? e.w : 0.f;
+                xr[n][i] = e;
+            }
+        }
+        const f32x4 da = xr[n][2 * pr], db = xr[n][2 * pr + 1];
+        const float va = c == 0 ? da.x - da.z : c == 1 ? da.y + da.z : c == 2 ? da.z - da.y : da.y - da.w;
+        const float vb = c == 0 ? db.x - db.z : c == 1 ? db.y + db.z : c == 2 ? db.z - db.y : db.y - db.w;
+        // hi = fp16(s v) for both channels of the pair; the residual s v - hi, exact; lo = fp16 of it
+        unsigned hi, lo;
+        float ra, rb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(va), "v"(sv));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(vb), "v"(sv));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+            : "=v"(ra) : "v"(va), "v"(sv), "v"(hi));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=v"(rb) : "v"(vb), "v"(sv), "v"(hi));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
+        pkh[pr] = hi, pkl[pr] = lo;
+        if (pr == 1) {
+            *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 0) * V_PIECE) = u32x2v{pkh[0], pkh[1]};
+            *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 1) * V_PIECE) = u32x2v{pkl[0], pkl[1]};
+        }
+    };
+    auto stage_all = [&](int n, int buf) __attribute__((always_inline)) {
+        char *vbuf = ldsb + buf * V_BYTES;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) piece(n, k >> 1, k & 1, vbuf, edge);
+    };
+
+    // ---- A operand: fragments of (xi, channel block), [ky][block][piece], straight from the packed bank
+    const unsigned a_voff = (unsigned)(xi * 2 * FRAG + lane * 16);
+    const unsigned w_blk0 = (unsigned)(mtile * 2 * MB + wh * MB);
+    // MB = 1: the three kernel rows of a chunk, requested one chunk ahead; MB = 2 (half the registers
+    // left): two slots, kernel row by kernel row, each requested while the one before it runs
+    constexpr bool LEAN = MB == 2;
+    f16x8 af[LEAN ? 2 : 3][MB][2];
+    auto a_load = [&](int aslot, int ky, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            const unsigned ws = (unsigned)sgpr(
+                (int)(((w_blk0 + b) * (unsigned)a.n_chunks + (unsigned)chunk) * U_BLK + (unsigned)ky * U_KY));
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                af[aslot][b][q] = __builtin_bit_cast(
+                    f16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff + q * FRAG, ws, 0));
+        }
+    };
+
+    f32x16 acc[MB][4];
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
+
+    // B fragments of block blk = 4 ky + j of a chunk, j = (m, s): rows 4m + s + ky and two below
+    const unsigned b_base = (unsigned)(xi * 2 * V_PIECE + ((l31 >> 4) * 2 * TX + (l31 & 15)) * 32 +
+                                       ((half * 16) ^ ((l31 & 8) << 1)));
+    f16x8 bq[2][2];
+    auto b_read = [&](int slot, int buf, int blk) __attribute__((always_inline)) {
+        const int j = blk & 3, ky = blk >> 2;
+        const char *vb = ldsb + buf * V_BYTES + b_base + (4 * (j >> 1) + (j & 1) + ky) * TX * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bq[slot][q] = *reinterpret_cast<const f16x8 *>(vb + q * V_PIECE);
+    };
+
+    // ---- prologue
+    x_load(0, c_begin);
+    if (n_units == 2) x_load(1, c_begin);
+    if (LEAN) {
+        a_load(0, 0, c_begin);
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a_load(ky, ky, c_begin);
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[b][j]));
+    stage_all(0, 0);
+    if (c_begin + 1 < c_end) x_load(0, c_begin + 1);
+    if (n_units == 2) {
+        stage_all(1, 0);
+        if (c_begin + 1 < c_end) x_load(1, c_begin + 1);
+    }
+    lds_barrier();
+    b_read(0, 0, 0);
+
+    // ---- main loop.  Twelve blocks of 3 MB MFMAs per chunk; the B fragments of a block are read
+    // while the block before it runs; the hand-over barrier sits before the last block (every
+    // wave has issued its last reads of this chunk and written its share of the next by then).
+    // The staging pieces are dealt out behind the MFMAs; sched_barrier pins the order.
+    constexpr int PER_BLK = 3 * MB, SLOTS = 11 * PER_BLK;     // slots in front of the barrier
+    // unit 0's eight pieces (one component of one channel pair each) sit behind slots 1, 1 + STEP, ...;
+    // unit 1 (waves 0 and 1 only: a uniform branch) comes as four groups of one component each, between them
+    constexpr int STEP = (SLOTS - 2) / 12;
+    const bool two = n_units == 2;
+    auto run_chunk = [&](auto buf_c, int chunk, auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr int BUF = decltype(buf_c)::value, buf = BUF;
+        char *vnext = ldsb + (buf ^ 1) * V_BYTES;
+        static_for<0, 12>([&](auto blk_c) __attribute__((always_inline)) {
+            constexpr int blk = decltype(blk_c)::value;
+            constexpr int ky = blk >> 2, j = blk & 3, slot = blk & 1;
+            if (blk == 11) {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (blk < 11) b_read(slot ^ 1, buf, blk + 1);
+            else if (MORE) b_read(0, buf ^ 1, 0);
+            static_for<0, PER_BLK>([&](auto m_c) __attribute__((always_inline)) {
+                constexpr int m = decltype(m_c)::value;
+                constexpr int b = m % MB, t = m / MB;      // t: 0 lo hi, 1 hi lo, 2 hi hi (smallest first)
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int as = LEAN ? (BUF + ky) & 1 : ky;
+                acc[b][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[as][b][t == 0 ? 1 : 0],
+                                                                   bq[slot][t == 1 ? 1 : 0], acc[b][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int s = blk * PER_BLK + m;
+                if (LEAN && j == 0 && m == 0 && !(STX_H2_SKIP & 2)) {      // the next kernel row's fragments
+                    if (ky < 2) a_load(as ^ 1, ky + 1, chunk);
+                    else if (MORE) a_load(as ^ 1, 0, chunk + 1);
+                }
+                if (MORE && !(STX_H2_SKIP & 1) && s >= 1 && (s - 1) % STEP == 0) {
+                    constexpr int k = (s - 1) / STEP;             // 0 .. 11
+                    if (k < 12 && k % 3 != 2) {                   // unit 0: pieces 0 .. 7
+                        constexpr int q = (k / 3) * 2 + k % 3;
+                        piece(0, q >> 1, q & 1, vnext, edge);
+                    } else if (k < 12 && two) {                   // unit 1: component k / 3
+                        asm volatile("");                         // (keeps this a scalar branch)
+                        piece(1, k / 3, 0, vnext, edge);
+                        piece(1, k / 3, 1, vnext, edge);
+                    }
+                }
+                if (MORE && !(STX_H2_SKIP & 4)) {
+                    if (s == 1 + 10 * STEP + 1 && chunk + 2 < c_end) x_load(0, chunk + 2);
+                    if (s == 1 + 11 * STEP + 1 && two && chunk + 2 < c_end) x_load(1, chunk + 2);
+                }
+            });
+            if (!LEAN && j == 3 && MORE && !(STX_H2_SKIP & 2)) a_load(ky, ky, chunk + 1);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    using b0 = std::integral_constant<int, 0>;
+    using b1 = std::integral_constant<int, 1>;
+#ifdef STX_H2_TIMING
+    const long long t_loop = clock64(), w_loop = wall_clock64();
+#endif
+    // stx_clock_marks: the workgroup in the middle of the launch times its chunk loop with both counters
+    const bool mark = a.clock_out != nullptr && (int)blockIdx.x == (int)(gridDim.x >> 1);
+    long long mark_c = 0, mark_w = 0;
+    if (mark) {
+        mark_c = clock64();
+        mark_w = wall_clock64();
+    }
+    {
+        int chunk = c_begin;
+        for (; chunk + 2 < c_end; chunk += 2) {
+            run_chunk(b0{}, chunk, yes{});
+            run_chunk(b1{}, chunk + 1, yes{});
+        }
+        // (an even number of chunks per launch or K slice: h2_usable, the slice bounds above)
+        run_chunk(b0{}, chunk, yes{});
+        run_chunk(b1{}, chunk + 1, no{});
+    }
+    if (mark) {
+        const long long dc = clock64() - mark_c, dw = wall_clock64() - mark_w;
+        if (tid == 0) {
+            a.clock_out[0] = dw >= 100 ? dc : 0;
+            a.clock_out[1] = dw >= 100 ? dw : 0;
+        }
+    }
+#ifdef STX_H2_TIMING
+    const long long t_end = clock64(), w_end = wall_clock64();
+#endif
+
+    // ---- epilogue.  Components through LDS, [xi][wh][j][rq][lane] x (registers 4 rq .. 4 rq + 3), one
+    // 32-channel block per wave and pass.  Then wave (hh, m, rqp) finishes pixel blocks (m, 0) and (m, 1)
+    // of channel block hh for register quads 2 rqp, 2 rqp + 1: per lane and channel (D register r of a
+    // block is channel (r & 3) + 8 (r >> 2) + 4 half) the 2 x 2 window at rows y, y + 1, columns x, x + 1.
+    float s_scale = 0.f, c_scale = 0.f;
+    if (EPI == kEpiDgradInject) {
+        const float n = (float)((size_t)a.M * HW);
+        if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
+        if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
+    }
+    const int hh = wave & 1, mrow = (wave >> 1) & 1, rqp = wave >> 2;
+    const bool weven = (a.W & 1) == 0;
+    const int yy = y0 + 4 * mrow + 2 * (l31 >> 4), xx0 = x0 + 2 * (l31 & 15);
+    const unsigned plane_bytes = (unsigned)a.M * HW4;
+    unsigned vo[2][2];                        // [row][column] of the lane's 2 x 2 outputs
+    {
+        const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                vo[y][e] = (yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u : kOob;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.mask), 0, a.mask ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rft = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_codes, 0, a.pool_codes ? a.M * ph * pw : 0, 0x00020000);
+    const unsigned vpool = (yy < a.H && xx0 < a.W)
+                               ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
+                               : kOob;
+    const int M_ = a.M;
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, auto even_c) __attribute__((always_inline)) {
+        if (decltype(even_c)::value)
+            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y][0], so, 0));
+        f32x2 v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][0], so, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
+        return v;
+    };
+    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
+                   __attribute__((always_inline)) {
+        if (decltype(even_c)::value) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
+        } else {
+            const float v0 = v.x, v1 = v.y;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, vo[y][1], so, 0);
+        }
+    };
+    const float *const content = a.inj.content;
+    const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
+              cw_ox = a.inj.win.ox - a.inj.win.sx;
+    int crow[2] = {0, 0}, ccol[2] = {0, 0};     // common.h: content_index, once per lane
+    if (EPI == kEpiDgradInject && content) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const bool ok = yy + y < a.H && xx0 < a.W;
+            int r = (cw_oy + (ok ? yy + y : 0)) % cw_ch;
+            crow[y] = (r < 0 ? r + cw_ch : r) * cw_cw;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = yy < a.H && xx0 < a.W;
+            const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
+            int r = (cw_ox + x) % cw_cw;
+            ccol[e] = r < 0 ? r + cw_cw : r;
+        }
+    }
+    float amax = 0.f;                          // max |y| over what this lane stores
+    f32x4 *ex = reinterpret_cast<f32x4 *>(ldsb);
+
+    auto tail = [&](int pass, auto even_c) __attribute__((always_inline)) {
+        const int cblk = m0 + (hh * MB + pass) * 32;
+#pragma unroll
+        for (int rqi = 0; rqi < 2; ++rqi) {
+            const int rq = 2 * rqp + rqi;
+            f32x4 o[2][2];                     // [row s][column]: four channels each
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 p[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) p[c] = ex[(((c * 2 + hh) * 4 + 2 * mrow + s) * 4 + rq) * 64 + lane];
+                o[s][0] = (p[0] + p[1] + p[2]) * out_scale;
+                o[s][1] = (p[1] - p[2] - p[3]) * out_scale;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c0 = cblk + e + 8 * rq;
+                const int c = sgpr(c0 < M_ ? c0 : M_);
+                const unsigned so = (unsigned)c * HW4;
+                f32x2 v[2];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) v[y] = f32x2{o[y][0][e], o[y][1][e]};
+                if (EPI == kEpiForward) {
+                    if (a.bias) {
+                        const float bs = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)half * 16u, (unsigned)c * 4u, 0));
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) v[y].x += bs, v[y].y += bs;
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) v[y].x = fmaxf(v[y].x, 0.f), v[y].y = fmaxf(v[y].y, 0.f);
+                    }
+                } else if (EPI != kEpiPartial) {
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        if (a.mask) {
+                            const f32x2 mk = ld2(rmask, y, so, even_c);
+                            v[y].x = mk.x > 0.f ? v[y].x : 0.f;
+                            v[y].y = mk.y > 0.f ? v[y].y : 0.f;
+                        }
+                        if (EPI == kEpiDgradInject) {
+                            if (content) {
+                                const f32x2 ft = ld2(rft, y, so, even_c);
+                                const int mm = c + 4 * half;
+                                const int cm = mm < a.M ? mm : 0;     // (lanes past M store nothing)
+                                const float *cp = content + (size_t)cm * cw_ch * cw_cw + crow[y];
+                                v[y].x += c_scale * (ft.x - cp[ccol[0]]);
+                                v[y].y += c_scale * (ft.y - cp[ccol[1]]);
+                            }
+                            if (a.inj.sgrad) {
+                                const f32x2 sg = ld2(rsg, y, so, even_c);
+                                v[y].x += s_scale * sg.x;
+                                v[y].y += s_scale * sg.y;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    if (EPI != kEpiForward || !a.skip_y) st2(ry, y, so, v[y], even_c);
+                    if (EPI != kEpiPartial)
+                        amax = fmaxf(amax, fmaxf(vo[y][0] != kOob ? fabsf(v[y].x) : 0.f,
+                                                 vo[y][1] != kOob ? fabsf(v[y].y) : 0.f));
+                }
+                // the lane's 2x2 outputs are one window of the 2x2/2 pooling layer that follows
+                // (pool.hip's arithmetic; ceil mode: the second row may be missing)
+                if (EPI == kEpiForward && a.pool_out) {
+                    const bool hy = yy + 1 < a.H;
+                    float pr;
+                    if (a.pool_mode == STX_POOL_MAX) {
+                        pr = fmaxf(v[0].x, v[0].y);
+                        pr = hy ? fmaxf(fmaxf(pr, v[1].x), v[1].y) : pr;
+                    } else {
+                        pr = (v[0].x + v[0].y + (hy ? v[1].x : 0.f) + (hy ? v[1].y : 0.f)) * (hy ? 0.25f : 0.5f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, vpool,
+                                                          (unsigned)c * (unsigned)(ph * pw * 4), 0);
+                    if (a.pool_codes) {
+                        const unsigned code = a.pool_mode == STX_POOL_MAX
+                                                  ? pool_max_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy)
+                                                  : pool_ave_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rcodes, vpool >> 2,
+                                                             (unsigned)c * (unsigned)(ph * pw), 0);
+                    }
+                }
+            }
+        }
+    };
+    static_for<0, MB>([&](auto pass_c) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_c)::value;
+        __syncthreads();          // the last B reads (pass 0) / the previous pass's reads are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                ex[(((xi * 2 + wh) * 4 + j) * 4 + rq) * 64 + lane] =
+                    f32x4{acc[pass][j][4 * rq], acc[pass][j][4 * rq + 1], acc[pass][j][4 * rq + 2],
+                          acc[pass][j][4 * rq + 3]};
+        __syncthreads();
+        if (weven) tail(pass, yes{});
+        else tail(pass, no{});
+    });
+    // max |y| of this launch's output, for the kernel that reads it next: one atomic per wave
+    if (EPI != kEpiPartial && a.y_amax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+        if (lane == 0) atomicMax(a.y_amax + ((blockIdx.x * 8 + wave) & 15), __builtin_bit_cast(unsigned, amax));
+    }
+#ifdef STX_H2_TIMING
+    if (blockIdx.x == gridDim.x - 3 && lane == 0) {     // a workgroup of the last round
+        g_h2_timing[wave][0] = t_loop - t_start, g_h2_timing[wave][1] = t_end - t_loop;
+        g_h2_timing[wave][2] = clock64() - t_end;
+        g_h2_timing[wave][3] = w_loop - w_start, g_h2_timing[wave][4] = w_end - w_loop;
+        g_h2_timing[wave][5] = wall_clock64() - w_end;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// max |x| of an array into sixteen slots of float bits (zeroed here first): what conv_h2_kernel needs
+// of its input when the kernel that wrote it left nothing (the first layer's output, a pooled blob
+// whose producer did not fuse, the gradient the loss terms start from).
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *slots) {
+    float m = 0.f;
+    const size_t n4 = n >> 2;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 15), __builtin_bit_cast(unsigned, m));
+}
+
+int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots) {
+    STX_HIP(hipMemsetAsync(slots, 0, kAmaxSlots * sizeof(unsigned), s));
+    if ((reinterpret_cast<size_t>(x) & 15) != 0) {
+        set_error("absmax_launch: unaligned array");
+        return STX_ERR_ARG;
+    }
+    const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+    absmax_kernel<<<blocks, 256, 0, s>>>(x, n, slots);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t h2_packed_floats(int K, int M) {
+    return (size_t)ceil_div(M, 32) * ceil_div(K, KC) * (U_BLK / 4) + kHeaderFloats;
+}
+
+// (G g)[xi] of kernel row ky of the filter W(m, k), fp32 -- the same expression in both passes
+__device__ __forceinline__ float h2_u(const float *__restrict__ w, int Ko, int transpose_flip, int m, int k,
+                                      int ky, int x) {
+    float g[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int t = ky * 3 + b;
+        g[b] = transpose_flip ? w[((size_t)k * Ko + m) * 9 + (8 - t)] : w[((size_t)m * Ko + k) * 9 + t];
+    }
+    return x == 0 ? g[0] : x == 1 ? (g[0] + g[1] + g[2]) * 0.5f : x == 2 ? (g[0] - g[1] + g[2]) * 0.5f : g[2];
+}
+
+__global__ void h2_bank_max_kernel(const float *__restrict__ w, int Ko, int transpose_flip, int M, int K,
+                                   unsigned *header) {
+    const size_t total = (size_t)M * K * 12;
+    float mx = 0.f;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = idx % 4, ky = (idx / 4) % 3;
+        const size_t mk = idx / 12;
+        mx = fmaxf(mx, fabsf(h2_u(w, Ko, transpose_flip, (int)(mk / K), (int)(mk % K), ky, x)));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(header, __builtin_bit_cast(unsigned, mx));
+}
+
+// packed[mblk][chunk][ky][xi][piece][half][l31][e] (fp16) = piece of s (G g)[xi] of kernel row ky of the
+// filter W(m = mblk*32 + l31, k = chunk*16 + half*8 + e); header[1] = the exponent of s
+__global__ void h2_pack_kernel(const float *__restrict__ w, int Ko, int transpose_flip, int M, int K,
+                               int n_chunks, unsigned short *__restrict__ packed, size_t total,
+                               unsigned *header) {
+    const int ew = h2_scale_exp(header[0]);
+    const float sw = pow2f(ew);
+    if (blockIdx.x == 0 && threadIdx.x == 0) header[1] = (unsigned)ew;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int e = r % 8; r /= 8;
+        const int l31 = r % 32; r /= 32;
+        const int half = r % 2; r /= 2;
+        const int piece = r % 2; r /= 2;
+        const int x = r % 4; r /= 4;
+        const int ky = r % 3; r /= 3;
+        const int chunk = r % n_chunks;
+        const int mblk = r / n_chunks;
+        const int m = mblk * 32 + l31, k = chunk * KC + half * 8 + e;
+        _Float16 out = (_Float16)0.f;
+        if (m < M && k < K) {
+            const float u = h2_u(w, Ko, transpose_flip, m, k, ky, x) * sw;
+            const _Float16 hi = (_Float16)u;
+            out = piece == 0 ? hi : (_Float16)(u - (float)hi);
+        }
+        packed[idx] = __builtin_bit_cast(unsigned short, out);
+    }
+}
+
+int h2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip, float *packed) {
+    const int M = transpose_flip ? Ko : Mo;
+    const int K = transpose_flip ? Mo : Ko;
+    const size_t bank_floats = h2_packed_floats(K, M) - kHeaderFloats;
+    unsigned *header = reinterpret_cast<unsigned *>(packed + bank_floats);
+    STX_HIP(hipMemsetAsync(header, 0, kHeaderFloats * sizeof(float), s));
+    h2_bank_max_kernel<<<(int)std::min<size_t>(((size_t)M * K * 12 + 255) / 256, 4096), 256, 0, s>>>(
+        w_caffe, Ko, transpose_flip, M, K, header);
+    STX_CHECK_LAUNCH();
+    const size_t total = bank_floats * 2;
+    h2_pack_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, s>>>(
+        w_caffe, Ko, transpose_flip, M, K, ceil_div(K, KC), reinterpret_cast<unsigned short *>(packed), total,
+        header);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+ConvConfig h2_config(int mb) {
+    ConvConfig c;
+    c.id = 300 + (mb == 2 ? 1 : 0);
+    c.bm = 64 * (mb == 2 ? 2 : 1);
+    c.kc = KC;
+    c.pr = PR;
+    c.pc = PC;
+    c.threads = NT;
+    c.lds_bytes = kLdsBytes;
+    return c;
+}
+
+// What the kernel takes: a multiple of 32 input channels (the chunk loop runs two chunks per trip), plane sets under 2 GiB, no ReLU nibbles.
+bool h2_usable(const ConvProblem &p) {
+    if (p.ksize != 3 || p.K % (2 * KC) != 0 || p.K < 2 * KC) return false;
+    if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return false;
+    if (p.wants_codes || p.in_codes || p.mask_codes) return false;
+    const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
+    const double wb = 4.0 * (double)h2_packed_floats(p.K, p.M);
+    return xb < 2147483648.0 && yb < 2147483648.0 && wb < 2147483648.0;
+}
+
+// K split of a launch and the channel tiling: the round model of conv_wino2.hip with this kernel's
+// measured chunk (16 channels: 2.0 us for 64 channels x 256 pixels, 2.75 us for 128 channels) and its
+// prologue + epilogue (8.5 / 17 us) -- whole rounds of 256 workgroups plus the reduce pass over the
+// slices.  Shape and epilogue only, never timing.
+static double h2_plan(int mb, const ConvProblem &p, int *factor) {
+    const int n_pairs = p.K / (2 * KC);
+    const long n = (long)ceil_div(p.M, 64 * mb) * ceil_div(p.H, PR) * ceil_div(p.W, PC);
+    const double out_mb = 4e-6 * p.M * (double)p.H * p.W;
+    const double t_chunk = mb == 2 ? 2.75 : 2.0, t_fixed = mb == 2 ? 17.0 : 8.5;
+    const bool may_split = p.epilogue == kEpiForward || p.epilogue == kEpiDgrad;
+    double best_cost = 0;
+    int best = 1;
+    for (int f = 1; f <= 8 && (f == 1 || (may_split && n_pairs / f >= 2)); ++f) {
+        const double rounds = (double)ceil_div((int)std::min<long>(n * f, 1 << 30), 256);
+        double c = rounds * (2.0 * ceil_div(n_pairs, f) * t_chunk + t_fixed);
+        if (f > 1) c += (f + 1) * out_mb / 3.0 + 5.0;      // reduce pass at ~3 TB/s + its launch
+        if (f == 1 || c < best_cost) {
+            best_cost = c;
+            best = f;
+        }
+    }
+    *factor = best;
+    return best_cost;
+}
+
+int h2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
+    int f;
+    h2_plan(cfg.bm / 64, p, &f);
+    return f;
+}
+
+ConvConfig h2_pick_config(const ConvProblem &p) {
+    int f1, f2;
+    if (p.M % 128 != 0) return h2_config(1);
+    return h2_plan(2, p, &f2) < h2_plan(1, p, &f1) ? h2_config(2) : h2_config(1);
+}
+
+bool h2_fuses_pool(const ConvProblem &p) {
+    return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
+           (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
+}
+
+template <int EPI, int MB>
+static int h2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
+    auto kern = conv_h2_kernel<EPI, MB>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(lds=%zu): %s", kLdsBytes, hipGetErrorString(e));
+        return STX_ERR_HIP;
+    }
+    kern<<<n_wg, NT, kLdsBytes, s>>>(args);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    if (!h2_usable(p) || !p.x_amax) {
+        set_error("h2_launch: unsupported problem (K %d, epilogue %d, input maximum %s)", p.K, p.epilogue,
+                  p.x_amax ? "given" : "missing");
+        return STX_ERR_UNSUPPORTED;
+    }
+    const int mb = cfg.bm / 64;
+    WinoArgs a;
+    a.x = p.x;
+    a.w = p.w;
+    a.y = p.y;
+    a.bias = p.bias;
+    a.mask = p.mask;
+    a.K = p.K;
+    a.M = p.M;
+    a.H = p.H;
+    a.W = p.W;
+    a.n_chunks = p.K / KC;
+    a.tiles_x = ceil_div(p.W, PC);
+    a.tiles_y = ceil_div(p.H, PR);
+    a.m_tiles = ceil_div(p.M, cfg.bm);
+    a.ksplit = 1;
+    a.w_tile_stride = 0;
+    a.relu = p.relu;
+    a.inj = p.inject;
+    a.pool_out = nullptr;
+    a.pool_codes = nullptr;
+    a.pool_mode = p.pool_mode;
+    a.x_bytes = (int)(4.0 * p.K * (double)p.H * p.W);
+    a.w_bytes = (int)(4 * (h2_packed_floats(p.K, p.M) - kHeaderFloats));
+    a.clock_out = p.clock_out;
+    a.x_amax = p.x_amax;
+    a.y_amax = p.y_amax;
+    const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
+    int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
+    const bool split = ksplit > 1 && p.splitk_ws && p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
+    if (split) {
+        a.ksplit = ksplit;
+        a.y = p.splitk_ws;
+        a.y_amax = nullptr;
+        n_wg *= ksplit;
+    } else if (h2_fuses_pool(p)) {
+        a.pool_out = p.pool_out;
+        a.pool_codes = p.pool_codes;
+        a.skip_y = p.skip_y && p.pool_codes != nullptr;
+    }
+    const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
+#define STX_H2_CASE(E)                                                                  \
+    case E:                                                                             \
+        STX_TRY(mb == 2 ? (h2_launch_epi<E, 2>(s, a, n_wg)) : (h2_launch_epi<E, 1>(s, a, n_wg))); \
+        break;
+    switch (epi) {
+        STX_H2_CASE(kEpiForward)
+        STX_H2_CASE(kEpiDgrad)
+        STX_H2_CASE(kEpiDgradInject)
+        STX_H2_CASE(kEpiPartial)
+        default:
+            set_error("h2_launch: no kernel for epilogue %d", p.epilogue);
+            return STX_ERR_UNSUPPORTED;
+    }
+#undef STX_H2_CASE
+    return split ? splitk_reduce_launch(s, p, ksplit) : STX_OK;
+}
+
+}  // namespace stx

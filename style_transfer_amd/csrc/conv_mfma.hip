@@ -484,10 +484,11 @@ struct SplitReduceArgs {
     const float *bias, *mask;
     ConvInject inj;
     int ksplit, M, HW, W, relu, epilogue;
+    unsigned *y_amax;       // ConvProblem::y_amax (or null): max |y| of what the pass writes
 };
 
-__device__ __forceinline__ void splitk_reduce_element(const SplitReduceArgs &a, size_t n, size_t i, float s_scale,
-                                                      float c_scale) {
+__device__ __forceinline__ float splitk_reduce_element(const SplitReduceArgs &a, size_t n, size_t i, float s_scale,
+                                                       float c_scale) {
     float v = a.part[i];
     for (int k = 1; k < a.ksplit; ++k) v += a.part[(size_t)k * n + i];
     const int m = i / a.HW;
@@ -504,6 +505,16 @@ __device__ __forceinline__ void splitk_reduce_element(const SplitReduceArgs &a, 
         if (a.inj.sgrad) v += s_scale * a.inj.sgrad[i];
     }
     a.y[i] = v;
+    return fabsf(v);
+}
+
+// max |y| of a pass into the slots the next fp16-split convolution reads (conv_h2.hip): one atomic per wave
+__device__ __forceinline__ void splitk_reduce_amax(const SplitReduceArgs &a, float amax) {
+    if (!a.y_amax) return;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(a.y_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSlots - 1)), __builtin_bit_cast(unsigned, amax));
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
@@ -511,8 +522,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
     float s_scale = 0.f, c_scale = 0.f;
     if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / (float)n + kEps));
     if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / (float)n + kEps));
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        splitk_reduce_element(a, n, i, s_scale, c_scale);
+        amax = fmaxf(amax, splitk_reduce_element(a, n, i, s_scale, c_scale));
+    splitk_reduce_amax(a, amax);
 }
 
 // The same over the 64-channel x (pr x pc)-pixel patches of a range of 2-D Winograd work items
@@ -533,16 +546,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_items_kernel(SplitReduceArg
     wino2_item_tiles(r.item_base + (int)(blockIdx.x / kItemBlocks), r.m_tiles, r.tiles_x * r.tiles_y, pt, mt);
     const int y0 = (pt / r.tiles_x) * r.pr, x0 = (pt % r.tiles_x) * r.pc, m0 = mt * 64;
     const int patch = r.pr * r.pc, total = 64 * patch;
+    float amax = 0.f;
     for (int e = (int)(blockIdx.x % kItemBlocks) * 256 + (int)threadIdx.x; e < total; e += kItemBlocks * 256) {
         const int mm = e / patch, rem = e - mm * patch;
         const int yy = y0 + rem / r.pc, xx = x0 + rem % r.pc, m = m0 + mm;
         if (m < a.M && yy < r.H && xx < a.W)
-            splitk_reduce_element(a, n, (size_t)m * a.HW + (size_t)yy * a.W + xx, s_scale, c_scale);
+            amax = fmaxf(amax, splitk_reduce_element(a, n, (size_t)m * a.HW + (size_t)yy * a.W + xx, s_scale, c_scale));
     }
+    splitk_reduce_amax(a, amax);
 }
 
 int conv_splitk_factor(const ConvConfig &cfg, const ConvProblem &p, bool packed) {
     if (!packed || p.ksize != 3 || (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad)) return 1;
+    if (cfg.id >= 300) return h2_splitk_factor(cfg, p);
     if (cfg.id >= 200) return wino2_splitk_factor(cfg, p);
     if (cfg.id == 3 || cfg.id == 4 || cfg.id == 8) return 1;   // (ids 100-102: 1-D Winograd, allowed)
     const int n_wg = conv_num_workgroups(cfg, p.M, p.H, p.W);
@@ -684,6 +700,7 @@ static SplitReduceArgs splitk_reduce_args(const ConvProblem &p, int ksplit) {
     r.W = p.W;
     r.relu = p.relu;
     r.epilogue = p.epilogue;
+    r.y_amax = p.y_amax;
     return r;
 }
 

@@ -321,6 +321,7 @@ static const WinoVariant kWino[] = {
 };
 
 ConvConfig wino_config_by_id(int id) {
+    if (id >= 200) return h2_config(id - 200 + 1);
     if (id >= 110) return wino4_config(id - 110);
     if (id >= 100) return wino2_config(id - 100);
     const WinoVariant &v = kWino[id];
@@ -337,6 +338,7 @@ ConvConfig wino_config_by_id(int id) {
 }
 
 size_t wino_packed_floats(const ConvConfig &cfg, int K, int M) {
+    if (cfg.id >= 300) return h2_packed_floats(K, M);
     if (cfg.id >= 200) return wino2_packed_floats(K, M);
     const size_t kpad = (size_t)ceil_div(K, cfg.kc) * cfg.kc;
     return (size_t)ceil_div(M, cfg.bm) * kpad * 12 * cfg.bm;
@@ -375,6 +377,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Mo, int Ko, in
 
 int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
                       const ConvConfig &cfg, float *packed) {
+    if (cfg.id >= 300) return h2_pack_weights(s, w_caffe, Mo, Ko, transpose_flip, packed);
     if (cfg.id >= 200) return wino2_pack_weights(s, w_caffe, Mo, Ko, transpose_flip, packed);
     const int M = transpose_flip ? Ko : Mo;
     const int K = transpose_flip ? Mo : Ko;
@@ -413,6 +416,7 @@ STX_WINO_VARIANT(2, 4, 2, 1, 1, 4, 4, 1)
 
 // Launches a Winograd configuration (cfg.id >= 100); `w` must come from wino_pack_weights.
 int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    if (cfg.id >= 300) return h2_launch(s, cfg, p, ksplit);
     if (cfg.id >= 200) return wino2_launch(s, cfg, p, ksplit);
     WinoArgs a;
     a.x = p.x;

@@ -82,6 +82,11 @@ struct Blob {
     DevBuf relu_codes;        // rectified blobs: sign nibbles per 2x2 window (ConvProblem::in_codes),
     bool relu_codes_valid = false;   // written by the forward pass of the convolution that reads the blob
     bool relu_codes_wanted = false;  // ... or would have been, had its kernel taken them (ConvProblem::wants_codes)
+    // max |data| / max |diff| (or an upper bound of it) on the device, for the fp16-split convolution
+    // that reads the blob (conv_h2.hip): the slot group (a blob index) of the engine's table that
+    // holds it -- the blob's own when its producer tracked it, the blob's below / above when a
+    // pooling layer passed the bound on -- or -1 when nobody has left one in this pass
+    int amax_data = -1, amax_diff = -1;
     size_t count() const { return (size_t)channels * h * w; }
 };
 
@@ -153,6 +158,10 @@ struct stx_engine {
     std::shared_ptr<SharedState> sh;   // weights, packed banks, targets (shared per GPU)
 
     DevBuf splitk;                     // split-K partial sums of small-plane convolutions
+    DevBuf amax;                       // [data | diff][blob][kAmaxSlots] words of float bits (Blob::amax_data)
+    unsigned *amax_slots(int blob, bool diff) const {
+        return static_cast<unsigned *>(amax.ptr) + ((size_t)(diff ? blobs.size() : 0) + blob) * kAmaxSlots;
+    }
     // the first layer leaves the Gram partials of its own output when that blob is a style tap of
     // the call (conv_first.hip): which blob, whether this call's forward pass wrote them, how many
     DevBuf first_gram;
@@ -338,7 +347,8 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
         set_error("weights of layer %s were never set", e->layers[layer].name.c_str());
         return STX_ERR_STATE;
     }
-    const int key = dir * 1024 + (cfg.id >= 200 ? 200 : cfg.id);   // the 2-D geometries share a bank
+    // (the 2-D geometries share a bank, so do the two channel tilings of the fp16-split kernel)
+    const int key = dir * 1024 + (cfg.id >= 300 ? 300 : cfg.id >= 200 ? 200 : cfg.id);
     auto it = cp.packed.find(key);
     if (it == cp.packed.end()) {
         const int M = dir ? cp.cin : cp.cout, K = dir ? cp.cout : cp.cin;
@@ -480,7 +490,7 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &problem
     ConvProblem p = problem;
     // stx_clock_marks: the eight-wave Winograd kernel times the chunk loop of one of its workgroups
     e->last_mark = -1;
-    if (e->clock_marks && cfg.id >= 200 && cfg.id < 210 && e->marks_used < kMaxClockMarks) {
+    if (e->clock_marks && ((cfg.id >= 200 && cfg.id < 210) || cfg.id >= 300) && e->marks_used < kMaxClockMarks) {
         e->last_mark = e->marks_used++;
         p.clock_out = static_cast<long long *>(e->marks_buf.ptr) + 2 * (size_t)e->last_mark;
     }
@@ -488,7 +498,9 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &problem
     // chosen kernel puts on the matrix cores (tile padding not counted)
     const double direct = 2.0 * p.M * p.K * p.ksize * p.ksize * (double)p.H * p.W;
     e->flop_algorithmic += direct;
-    e->flop_issued += cfg.id >= 200   ? direct * 4.0 / 9.0
+    // (ids 300+: 6 of 9 multiplies, each as three fp16 products of 1/16 of an fp32 MFMA's time per k)
+    e->flop_issued += cfg.id >= 300   ? direct * (6.0 / 9.0) * (3.0 / 16.0)
+                      : cfg.id >= 200 ? direct * 4.0 / 9.0
                       : cfg.id >= 100 ? direct * 2.0 / 3.0
                                       : direct;
     if (cfg.id >= 100) return wino_launch(e->stream, cfg, p, conv_splitk_factor(cfg, p, true));
@@ -497,11 +509,47 @@ int launch_conv(stx_engine *e, const ConvConfig &cfg, const ConvProblem &problem
 
 // Which fused-pooling kernels also leave the window codes the backward pooling runs from: the
 // eight-wave 2-D Winograd kernel does, the four-wave one (ids 210+) writes the pooled values only.
-static bool conv_writes_pool_codes(const ConvConfig &cfg) { return cfg.id >= 200 && cfg.id < 210; }
+static bool conv_writes_pool_codes(const ConvConfig &cfg) { return (cfg.id >= 200 && cfg.id < 210) || cfg.id >= 300; }
 
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
+    if (cfg.id >= 300) return conv_splitk_factor(cfg, p, true) == 1 && h2_fuses_pool(p);
     return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
+}
+
+// The fp16-split kernel (conv_h2.hip) for this problem?  Layers with at least STX_CONV_H2 input
+// channels (default 256; 0: never), by shape and epilogue only -- never by timing: it rounds
+// differently from the fp32 kernels, and a given shape must always take the same path.
+// STX_CONV_ALGO=h2|h2a|h2b forces it (either / the 64- / the 128-channel tiling) wherever it applies.
+static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
+    const char *algo = getenv("STX_CONV_ALGO");
+    int force = 0;
+    if (algo && *algo) {
+        if (!strcmp(algo, "h2")) force = 3;
+        else if (!strcmp(algo, "h2a")) force = 1;
+        else if (!strcmp(algo, "h2b")) force = 2;
+        else return false;             // some other kernel family was asked for
+    }
+    const char *env = getenv("STX_CONV_H2");
+    const int min_k = env ? atoi(env) : 256;
+    if (!force && (min_k <= 0 || p.K < min_k || p.M < 64)) return false;
+    if (!h2_usable(p)) return false;
+    *out = force == 1 ? h2_config(1) : force == 2 ? h2_config(2) : h2_pick_config(p);
+    return true;
+}
+
+// The slots with max |x| of a blob's data / diff for a kernel that is about to read it: what its
+// producer left (Blob::amax_data / amax_diff), else a pass over the array now.
+static int amax_for(stx_engine *e, int blob, bool diff, const unsigned **out) {
+    Blob &b = e->blobs[blob];
+    int &src = diff ? b.amax_diff : b.amax_data;
+    if (src < 0) {
+        ProfScope scope(e, std::string("absmax ") + b.name, 0.0);
+        STX_TRY(absmax_launch(e->stream, diff ? b.diff.f() : b.data.f(), b.count(), e->amax_slots(blob, diff)));
+        src = blob;
+    }
+    *out = e->amax_slots(src, diff);
+    return STX_OK;
 }
 
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
@@ -529,6 +577,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         if (pooled) *pooled = false;
         b.relu_codes_valid = false;
         b.relu_codes_wanted = false;
+        t.amax_data = -1;
         float *gram = nullptr;
         if (L.top_blob == e->first_gram_blob) {
             const int parts = conv_first_workgroups(b.h, b.w);
@@ -544,10 +593,18 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         e->flop_issued += direct;
         return conv_first_launch(e->stream, p.x, cp.w.f(), cp.b.f(), p.y, cp.cin, b.h, b.w, p.relu, gram);
     }
-    b.relu_codes_wanted = relu_codes && b.relu && b.channels <= 128;      // (see below)
-    p.wants_codes = b.relu_codes_wanted;
     ConvConfig cfg;
-    STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
+    // the fp16-split kernel where it applies (it neither writes nor reads ReLU nibbles)
+    const bool h2 = h2_choice(p, &cfg);
+    b.relu_codes_wanted = !h2 && relu_codes && b.relu && b.channels <= 128;      // (see below)
+    p.wants_codes = b.relu_codes_wanted;
+    if (!h2) STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
+    t.amax_data = -1;
+    if (h2) {
+        STX_TRY(amax_for(e, L.bottom_blob, false, &p.x_amax));
+        p.y_amax = e->amax_slots(L.top_blob, false);
+        t.amax_data = L.top_blob;          // (a K-sliced launch leaves it through its reduce pass)
+    }
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 0, cfg, &packed));
     p.w = packed;
@@ -571,8 +628,10 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         p.pool_out = pt.data.f();
         p.pool_mode = pool->pool_mode;
         pt.codes_valid = false;
+        pt.amax_data = -1;
         if (conv_fuses_pool(cfg, p)) {
             *pooled = true;
+            pt.amax_data = t.amax_data;    // max (or mean) of 2x2 windows: the same bound
             if (conv_writes_pool_codes(cfg) && e->pool_codes) {
                 STX_TRY(pt.codes.ensure(pt.count()));
                 p.pool_codes = static_cast<unsigned char *>(pt.codes.ptr);
@@ -628,10 +687,18 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
         return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
     }
     ConvConfig cfg;
-    STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
+    const bool h2 = !p.wants_codes && h2_choice(p, &cfg);
+    if (!h2) STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
+    b.amax_diff = -1;
+    if (h2) {
+        p.mask_codes = nullptr;
+        STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
+        p.y_amax = e->amax_slots(L.bottom_blob, true);
+        b.amax_diff = L.bottom_blob;
+    }
     const float *packed = nullptr;
     STX_TRY(get_packed(e, li, 1, cfg, &packed));
     p.w = packed;
@@ -649,6 +716,10 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
             const std::function<int(int)> *after_blob = nullptr, bool relu_codes = false,
             const std::vector<char> *observed = nullptr) {
     int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
+    // the maxima the fp16-split convolutions leave for each other (Blob::amax_data): none yet
+    STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
+    STX_HIP(hipMemsetAsync(e->amax_slots(0, false), 0, e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
+    for (Blob &b : e->blobs) b.amax_data = -1;
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
         if (L.type == STX_LAYER_RELU || !needed[L.top_blob]) continue;
@@ -698,6 +769,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
                 }
                 STX_TRY(pool_forward_launch(e->stream, b.data.f(), b.channels, b.h, b.w, L.pool_mode,
                                             t.data.f(), codes));
+                t.amax_data = b.amax_data;      // (a ReLU behind it only lowers the maximum)
                 if (t.relu || L.top_blob == relu_blob)
                     STX_TRY(relu_inplace_launch(e->stream, t.data.f(), t.count()));
             }   // (the loss terms of a tapped pooled blob are timed under their own labels)
@@ -1057,6 +1129,7 @@ void stx_engine_destroy(stx_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &b : e->sgrad_tap) b->release();
     e->marks_buf.release();
+    e->amax.release();
     for (Blob &b : e->blobs) {
         b.data.release();
         b.diff.release();
@@ -1607,6 +1680,8 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
 
     // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
     int cur = order[0].blob;
+    STX_HIP(hipMemsetAsync(e->amax_slots(0, true), 0, e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
+    for (Blob &b : e->blobs) b.amax_diff = -1;
     {
         bool written = false;
         STX_TRY(inject(0, written));
@@ -1649,11 +1724,13 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             else
                 STX_TRY(pool_backward_launch(e->stream, top.diff.f(), bot.data.f(), bot.channels,
                                              bot.h, bot.w, L.pool_mode, bot.relu, bot.diff.f()));
+            bot.amax_diff = top.amax_diff;     // routing / averaging never raises the maximum
         }
         cur = L.bottom_blob;
         if (k >= 0 && !fused) {
             bool written = true;   // the upstream gradient is already in diff
             STX_TRY(inject((size_t)k, written));
+            bot.amax_diff = -1;    // (the terms were added behind the kernel that left the maximum)
         }
     }
     STX_TRY(end_timing(e));
@@ -1995,18 +2072,30 @@ static ConvConfig hook_config(stx_engine *e, int ksize, int K, int M, int H, int
     return conv_pick_config(ksize, K, M, H, W);
 }
 
+// The fp16-split kernel for a stand-alone operator call, by the tile path's rule; the input's maximum
+// comes from a pass over it, the output's goes to a scratch group of the table.
+static int hook_h2(stx_engine *e, ConvProblem &p, ConvConfig *cfg) {
+    ConvConfig h;
+    if (!h2_choice(p, &h)) return STX_OK;
+    *cfg = h;
+    STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
+    unsigned *scratch = e->amax_slots((int)e->blobs.size(), true);
+    STX_TRY(absmax_launch(e->stream, p.x, (size_t)p.K * p.H * p.W, scratch));
+    STX_HIP(hipMemsetAsync(scratch + kAmaxSlots, 0, kAmaxSlots * sizeof(unsigned), e->stream));
+    p.x_amax = scratch;
+    p.y_amax = scratch + kAmaxSlots;
+    return STX_OK;
+}
+
 int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, const float *w,
                         const float *b, int Cout, int ksize, int relu, float *y) {
     if (!e || !x || !w || !y) return STX_ERR_ARG;
     STX_TRY(e->set_device());
     if (conv_first_usable(Cin, Cout, ksize))      // the tile path's first-layer kernel
         return conv_first_launch(e->stream, x, w, b, y, Cin, H, W, relu, nullptr);
-    const ConvConfig cfg = hook_config(e, ksize, Cin, Cout, H, W);
-    const float *packed = nullptr;
-    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 0, cfg, &packed));
+    ConvConfig cfg = hook_config(e, ksize, Cin, Cout, H, W);
     ConvProblem p{};
     p.x = x;
-    p.w = packed;
     p.y = y;
     p.bias = b;
     p.K = Cin;
@@ -2016,6 +2105,10 @@ int stx_op_conv_forward(stx_engine *e, const float *x, int Cin, int H, int W, co
     p.ksize = ksize;
     p.relu = relu;
     p.epilogue = kEpiForward;
+    STX_TRY(hook_h2(e, p, &cfg));
+    const float *packed = nullptr;
+    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 0, cfg, &packed));
+    p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
     return launch_conv(e, cfg, p);
 }
@@ -2029,12 +2122,9 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
         STX_TRY(conv_small_pack(e->stream, w, Cout, Cin, 1, e->upload.f()));
         return conv_small_launch(e->stream, dy, e->upload.f(), dx, relu_mask_data, Cout, Cin, H, W);
     }
-    const ConvConfig cfg = hook_config(e, ksize, Cout, Cin, H, W);
-    const float *packed = nullptr;
-    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 1, cfg, &packed));
+    ConvConfig cfg = hook_config(e, ksize, Cout, Cin, H, W);
     ConvProblem p{};
     p.x = dy;
-    p.w = packed;
     p.y = dx;
     p.mask = relu_mask_data;
     p.K = Cout;
@@ -2043,6 +2133,10 @@ int stx_op_conv_backward_data(stx_engine *e, const float *dy, int Cout, int H, i
     p.W = W;
     p.ksize = ksize;
     p.epilogue = kEpiDgrad;
+    STX_TRY(hook_h2(e, p, &cfg));
+    const float *packed = nullptr;
+    STX_TRY(scratch_pack(e, w, Cout, Cin, ksize, 1, cfg, &packed));
+    p.w = packed;
     STX_TRY(attach_splitk(e, cfg, p));
     return launch_conv(e, cfg, p);
 }

@@ -22,7 +22,7 @@ CONV_CASES = [  # (Cin, Cout, H, W): SURVEY section 8c list + shapes that hit ev
     # degenerate planes and ragged channel counts (partial chunks, partial channel tiles)
     (8, 33, 1, 1), (9, 65, 2, 3), (24, 96, 5, 67), (130, 66, 31, 33)]
 # every convolution kernel family on every shape it accepts; None = the engine's own choice
-CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino2c', 'wino4a', 'wino4b', 'wino4c']
+CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino2c', 'wino4a', 'wino4b', 'wino4c', 'h2a', 'h2b']
 
 
 @pytest.mark.parametrize('algo', CONV_ALGOS)
@@ -58,6 +58,53 @@ def test_conv_forward_and_backward_data(cin, cout, h, w, algo, monkeypatch):
     lib.call('stx_op_conv_backward_data', eng.handle, ddy.ptr, cout, h, w, dw.ptr, cin, 3,
              dbelow.ptr, gx.ptr)
     assert max_rel(gx.get(), ref * (below > 0)) < 2e-5
+
+
+# The fp16-split kernel (conv_h2.hip: two fp16 pieces per operand, three products on the fp16 matrix
+# cores) scales its input by a power of two taken from the blob's own maximum, so no range may
+# overflow or lose more than the float32 kernels do: activations up to 2e4 and far beyond, gradients
+# whose elements span 1e-6 .. 1e3, tiny gradients, a blob of zeros.  Same 2e-5 bound as every kernel.
+H2_SHAPES = [(64, 64, 32, 32), (128, 256, 40, 41), (256, 128, 17, 70), (512, 512, 16, 16), (96, 160, 9, 33),
+             (256, 256, 64, 64)]
+H2_RANGES = {
+    'relu': lambda r, s: np.maximum(r.standard_normal(s) * 30 + 5, 0),
+    'to 2e4': lambda r, s: np.maximum(r.standard_normal(s), 0) * 5e3,
+    'to 1e30': lambda r, s: np.maximum(r.standard_normal(s), 0) * 2.5e29,
+    'grad 1e-6..1e3': lambda r, s: r.standard_normal(s) * 10.0 ** r.uniform(-6, 2.5, s),
+    'grad tiny': lambda r, s: r.standard_normal(s) * 10.0 ** r.uniform(-30, -24, s),
+    'one spike': lambda r, s: np.where(r.uniform(size=s) < 1e-4, 1e6, 1.0) * r.standard_normal(s),
+    'zeros': lambda r, s: np.zeros(s),
+}
+
+
+@pytest.mark.parametrize('algo', ['h2a', 'h2b'])
+@pytest.mark.parametrize('kind', sorted(H2_RANGES))
+@pytest.mark.parametrize('cin,cout,h,w', H2_SHAPES)
+def test_conv_fp16_split_over_input_ranges(cin, cout, h, w, kind, algo, monkeypatch):
+    monkeypatch.setenv('STX_CONV_ALGO', algo)
+    eng = gpu_engine()
+    rng = np.random.RandomState(cin + cout + h + len(kind))
+    x = H2_RANGES[kind](rng, (cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2 / (9 * cin))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout) * max(float(np.abs(x).max()), 1e-30)).astype(np.float32)
+    dx_, dw, db = eng.to_device(x), eng.to_device(wt), eng.to_device(b)
+    y = eng.empty((cout, h, w))
+    lib.call('stx_op_conv_forward', eng.handle, dx_.ptr, cin, h, w, dw.ptr, db.ptr, cout, 3, 0, y.ptr)
+    ref = L.conv_forward(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64))
+    if kind == 'zeros':
+        assert np.array_equal(y.get(), np.broadcast_to(b[:, None, None], ref.shape))
+    else:
+        assert max_rel(y.get(), ref) < 2e-5
+    # the same data as an upstream gradient of the transposed layer, with a mask
+    wt2 = (rng.standard_normal((cin, cout, 3, 3)) * np.sqrt(2 / (9 * cin))).astype(np.float32)
+    below = rng.standard_normal((cout, h, w)).astype(np.float32)
+    dw2, dbelow, gx = eng.to_device(wt2), eng.to_device(below), eng.empty((cout, h, w))
+    lib.call('stx_op_conv_backward_data', eng.handle, dx_.ptr, cin, h, w, dw2.ptr, cout, 3, dbelow.ptr, gx.ptr)
+    ref = L.conv_backward_data(x.astype(np.float64), wt2.astype(np.float64)) * (below > 0)
+    if kind == 'zeros':
+        assert not gx.get().any()
+    else:
+        assert max_rel(gx.get(), ref) < 2e-5
 
 
 @pytest.mark.parametrize('h,w', [(8, 8), (7, 9), (1, 5), (33, 2), (64, 96), (543, 37)])

@@ -56,19 +56,22 @@ def rel(x, ref):
 
 
 rng = np.random.RandomState(0)
-for c, hw in ((64, 65536), (128, 16384), (512, 4096)):
-    f = np.maximum(rng.standard_normal((c, hw)) * 30 + 5, 0).astype(np.float32)   # post-ReLU, biased
-    ref = f.astype(np.float64) @ f.astype(np.float64).T
-    print('Gram C=%d HW=%d:  split %.2e   fp32 blocks %.2e   numpy f32 %.2e   (two pieces only: %.2e)'
-          % (c, hw, rel(matmul_split(f, f.T), ref), rel(matmul_f32_blocks(f, f.T), ref),
-             rel(f @ f.T, ref),
-             rel(sum(np.float64(a) @ np.float64(b).T for a in split3(f)[:2] for b in split3(f)[:2]), ref)))
-    d = rng.standard_normal((c, c)).astype(np.float32)
-    d = np.tril(d) + np.tril(d, -1).T
-    ref = d.astype(np.float64) @ f.astype(np.float64)
-    print('SYMM C=%d HW=%d:  split %.2e   fp32 blocks %.2e   numpy f32 %.2e'
-          % (c, hw, rel(matmul_split(d, f, kb=64), ref), rel(matmul_f32_blocks(d, f, kb=64), ref),
-             rel(d @ f, ref)))
+
+
+def main_gemm():
+    for c, hw in ((64, 65536), (128, 16384), (512, 4096)):
+        f = np.maximum(rng.standard_normal((c, hw)) * 30 + 5, 0).astype(np.float32)   # post-ReLU, biased
+        ref = f.astype(np.float64) @ f.astype(np.float64).T
+        print('Gram C=%d HW=%d:  split %.2e   fp32 blocks %.2e   numpy f32 %.2e   (two pieces only: %.2e)'
+              % (c, hw, rel(matmul_split(f, f.T), ref), rel(matmul_f32_blocks(f, f.T), ref),
+                 rel(f @ f.T, ref),
+                 rel(sum(np.float64(a) @ np.float64(b).T for a in split3(f)[:2] for b in split3(f)[:2]), ref)))
+        d = rng.standard_normal((c, c)).astype(np.float32)
+        d = np.tril(d) + np.tril(d, -1).T
+        ref = d.astype(np.float64) @ f.astype(np.float64)
+        print('SYMM C=%d HW=%d:  split %.2e   fp32 blocks %.2e   numpy f32 %.2e'
+              % (c, hw, rel(matmul_split(d, f, kb=64), ref), rel(matmul_f32_blocks(d, f, kb=64), ref),
+                 rel(d @ f, ref)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -145,12 +148,18 @@ def conv_direct_f64(x, w):
     return out
 
 
-print()
-for c, hw in ((64, 24), (256, 16), (512, 12)):
-    x = np.maximum(rng.standard_normal((c, hw, hw)) * 30 + 5, 0).astype(np.float32)
-    w = (rng.standard_normal((64, c, 3, 3)) * np.sqrt(2 / (9 * c))).astype(np.float32)
-    ref = conv_direct_f64(x, w)
-    print('conv %3d -> 64 @ %dx%d:  bf16x3 1-D Winograd %.2e   with hi / lo accumulators %.2e   '
-          'float32 2-D Winograd %.2e' % (c, hw, hw, rel(conv_bf3_emulated(x, w, False), ref),
-                                         rel(conv_bf3_emulated(x, w, True), ref),
-                                         rel(conv_wino2_f32_emulated(x, w), ref)))
+def main_conv():
+    print()
+    for c, hw in ((64, 24), (256, 16), (512, 12)):
+        x = np.maximum(rng.standard_normal((c, hw, hw)) * 30 + 5, 0).astype(np.float32)
+        w = (rng.standard_normal((64, c, 3, 3)) * np.sqrt(2 / (9 * c))).astype(np.float32)
+        ref = conv_direct_f64(x, w)
+        print('conv %3d -> 64 @ %dx%d:  bf16x3 1-D Winograd %.2e   with hi / lo accumulators %.2e   '
+              'float32 2-D Winograd %.2e' % (c, hw, hw, rel(conv_bf3_emulated(x, w, False), ref),
+                                             rel(conv_bf3_emulated(x, w, True), ref),
+                                             rel(conv_wino2_f32_emulated(x, w), ref)))
+
+
+if __name__ == '__main__':
+    main_gemm()
+    main_conv()
