@@ -21,7 +21,7 @@
 // leave the vector pipe to the transform and the split.
 //
 // Scales.  No fp16 value can overflow, by construction: the kernel that wrote the input blob left
-// max |x| behind (sixteen slots of float bits, combined with atomicMax: `x_amax`), and this kernel
+// max |x| behind (kAmaxSlots words of float bits, combined with atomicMax: `x_amax`), and this kernel
 // scales its input by the power of two that puts that maximum into [2^13, 2^14) -- |V| < 2^15 < 65504.
 // The filter bank is scaled the same way when it is packed (its exponent sits behind the bank).  What
 // is small against the maximum loses relative precision only below 2^-17 of it.  The epilogue undoes
@@ -51,7 +51,8 @@
 
 #ifndef STX_H2_SKIP
 #define STX_H2_SKIP 0   // timing experiments (tools/ubench/h2conv_bench.hip): 1 no staging, 2 no filter
-#endif                 // loads, 4 no patch loads in the main loop.  Wrong results when non-zero.
+#endif                 // loads, 4 no patch loads in the main loop, 8 no stores, 16 no mask loads in the
+                       // epilogue.  Wrong results when non-zero.
 
 namespace stx {
 
@@ -75,7 +76,7 @@ constexpr int FRAG = 1024;                  // one operand fragment: 64 lanes x 
 constexpr int U_KY = 4 * 2 * FRAG;          // [xi][piece] of one (channel block, chunk, ky): 8 KB
 constexpr int U_BLK = 3 * U_KY;             // one (channel block, chunk): 24 KB
 constexpr int EX_BYTES = 4 * 2 * 4 * 4 * 64 * 16;   // epilogue exchange: 128 KB
-constexpr size_t kLdsBytes = EX_BYTES > 2 * V_BYTES ? EX_BYTES : 2 * V_BYTES;
+constexpr size_t kLdsBytes = (EX_BYTES > 2 * V_BYTES ? EX_BYTES : 2 * V_BYTES) + 64;    // + the waves' maxima
 constexpr int kHeaderFloats = 64;           // behind the bank: [0] max |U| (float bits), [1] the scale's exponent
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // ---- scales: the input's from the maximum its producer left, the bank's from its header
     unsigned amax_bits = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) amax_bits = max(amax_bits, a.x_amax[i]);
+    for (int i = 0; i < kAmaxSlots; ++i) amax_bits = max(amax_bits, a.x_amax[i]);
     const int es = sgpr(h2_scale_exp(amax_bits));
     const int ew = sgpr(reinterpret_cast<const int *>(a.w)[(a.w_bytes >> 2) + 1]);
     const float sv = pow2f(es);
@@ -434,6 +435,10 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     };
     auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
                    __attribute__((always_inline)) {
+        if (STX_H2_SKIP & 8) {        // (timing experiment: the epilogue without its stores)
+            if (v.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, vo[y][0], so, 0);
+            return;
+        }
         if (decltype(even_c)::value) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
         } else {
@@ -464,8 +469,45 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     float amax = 0.f;                          // max |y| over what this lane stores
     f32x4 *ex = reinterpret_cast<f32x4 *>(ldsb);
 
-    auto tail = [&](int pass, auto even_c) __attribute__((always_inline)) {
+    // One pass = the accumulators of one 32-channel block per wave.  Everything the pass reads from
+    // memory (bias; ReLU mask and style term: 128 KB each per workgroup, which all workgroups of a round
+    // want at the same moment) is requested BEFORE the exchange and lands during it -- read where it
+    // is used, every one of the sixteen loads of a lane exposed its full latency: 28 k cycles per
+    // epilogue of two passes instead of 12 k.
+    auto epilogue_pass = [&](auto pass_c, auto even_c) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_c)::value;
         const int cblk = m0 + (hh * MB + pass) * 32;
+        auto chan = [&](int n) __attribute__((always_inline)) {     // n = 4 rqi + e
+            const int c0 = cblk + (n & 3) + 8 * (2 * rqp + (n >> 2));
+            return sgpr(c0 < M_ ? c0 : M_);
+        };
+        float bs[8];
+        f32x2 mk[16], sg[16];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int c = chan(n);
+            const unsigned so = (unsigned)c * HW4;
+            if (EPI == kEpiForward) {
+                bs[n] = a.bias ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               rbias, (unsigned)half * 16u, (unsigned)c * 4u, 0))
+                               : 0.f;
+            } else if (EPI != kEpiPartial) {
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    if (a.mask && !(STX_H2_SKIP & 16)) mk[2 * n + y] = ld2(rmask, y, so, even_c);
+                    if (EPI == kEpiDgradInject && a.inj.sgrad) sg[2 * n + y] = ld2(rsg, y, so, even_c);
+                }
+            }
+        }
+        __syncthreads();          // the last B reads (pass 0) / the previous pass's reads are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                ex[(((xi * 2 + wh) * 4 + j) * 4 + rq) * 64 + lane] =
+                    f32x4{acc[pass][j][4 * rq], acc[pass][j][4 * rq + 1], acc[pass][j][4 * rq + 2],
+                          acc[pass][j][4 * rq + 3]};
+        __syncthreads();
 #pragma unroll
         for (int rqi = 0; rqi < 2; ++rqi) {
             const int rq = 2 * rqp + rqi;
@@ -480,18 +522,16 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c0 = cblk + e + 8 * rq;
-                const int c = sgpr(c0 < M_ ? c0 : M_);
+                const int n = 4 * rqi + e;
+                const int c = chan(n);
                 const unsigned so = (unsigned)c * HW4;
                 f32x2 v[2];
 #pragma unroll
                 for (int y = 0; y < 2; ++y) v[y] = f32x2{o[y][0][e], o[y][1][e]};
                 if (EPI == kEpiForward) {
                     if (a.bias) {
-                        const float bs = __builtin_bit_cast(
-                            float, __builtin_amdgcn_raw_buffer_load_b32(rbias, (unsigned)half * 16u, (unsigned)c * 4u, 0));
 #pragma unroll
-                        for (int y = 0; y < 2; ++y) v[y].x += bs, v[y].y += bs;
+                        for (int y = 0; y < 2; ++y) v[y].x += bs[n], v[y].y += bs[n];
                     }
                     if (a.relu) {
 #pragma unroll
@@ -500,13 +540,13 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 } else if (EPI != kEpiPartial) {
 #pragma unroll
                     for (int y = 0; y < 2; ++y) {
-                        if (a.mask) {
-                            const f32x2 mk = ld2(rmask, y, so, even_c);
-                            v[y].x = mk.x > 0.f ? v[y].x : 0.f;
-                            v[y].y = mk.y > 0.f ? v[y].y : 0.f;
+                        if (a.mask && !(STX_H2_SKIP & 16)) {
+                            v[y].x = mk[2 * n + y].x > 0.f ? v[y].x : 0.f;
+                            v[y].y = mk[2 * n + y].y > 0.f ? v[y].y : 0.f;
                         }
                         if (EPI == kEpiDgradInject) {
                             if (content) {
+                                // (one layer per tile evaluation takes this: read where it is used)
                                 const f32x2 ft = ld2(rft, y, so, even_c);
                                 const int mm = c + 4 * half;
                                 const int cm = mm < a.M ? mm : 0;     // (lanes past M store nothing)
@@ -515,9 +555,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                                 v[y].y += c_scale * (ft.y - cp[ccol[1]]);
                             }
                             if (a.inj.sgrad) {
-                                const f32x2 sg = ld2(rsg, y, so, even_c);
-                                v[y].x += s_scale * sg.x;
-                                v[y].y += s_scale * sg.y;
+                                v[y].x += s_scale * sg[2 * n + y].x;
+                                v[y].y += s_scale * sg[2 * n + y].y;
                             }
                         }
                     }
@@ -554,24 +593,22 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         }
     };
     static_for<0, MB>([&](auto pass_c) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pass_c)::value;
-        __syncthreads();          // the last B reads (pass 0) / the previous pass's reads are done
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                ex[(((xi * 2 + wh) * 4 + j) * 4 + rq) * 64 + lane] =
-                    f32x4{acc[pass][j][4 * rq], acc[pass][j][4 * rq + 1], acc[pass][j][4 * rq + 2],
-                          acc[pass][j][4 * rq + 3]};
-        __syncthreads();
-        if (weven) tail(pass, yes{});
-        else tail(pass, no{});
+        if (weven) epilogue_pass(pass_c, yes{});
+        else epilogue_pass(pass_c, no{});
     });
-    // max |y| of this launch's output, for the kernel that reads it next: one atomic per wave
+    // max |y| of this launch's output, for the kernel that reads it next: one atomic per workgroup
+    // (thousands of atomics on a few words take longer than the kernel's last round)
     if (EPI != kEpiPartial && a.y_amax) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
-        if (lane == 0) atomicMax(a.y_amax + ((blockIdx.x * 8 + wave) & 15), __builtin_bit_cast(unsigned, amax));
+        float *wmax = reinterpret_cast<float *>(ldsb + kLdsBytes - 64);
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 8; ++w) amax = fmaxf(amax, wmax[w]);
+            atomicMax(a.y_amax + (blockIdx.x & (kAmaxSlots - 1)), __builtin_bit_cast(unsigned, amax));
+        }
     }
 #ifdef STX_H2_TIMING
     if (blockIdx.x == gridDim.x - 3 && lane == 0) {     // a workgroup of the last round
@@ -584,7 +621,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// max |x| of an array into sixteen slots of float bits (zeroed here first): what conv_h2_kernel needs
+// max |x| of an array into kAmaxSlots words of float bits (zeroed here first): what conv_h2_kernel needs
 // of its input when the kernel that wrote it left nothing (the first layer's output, a pooled blob
 // whose producer did not fuse, the gradient the loss terms start from).
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *slots) {
@@ -598,7 +635,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 15), __builtin_bit_cast(unsigned, m));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)          // one atomic per block: they serialise on the few words
+        atomicMax(slots + (blockIdx.x & (kAmaxSlots - 1)),
+                  __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots) {
@@ -607,7 +649,7 @@ int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots) {
         set_error("absmax_launch: unaligned array");
         return STX_ERR_ARG;
     }
-    const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 2048);
+    const int blocks = (int)std::min<size_t>((n / 4 + 2047) / 2048 + 1, 1024);
     absmax_kernel<<<blocks, 256, 0, s>>>(x, n, slots);
     STX_CHECK_LAUNCH();
     return STX_OK;
@@ -642,7 +684,11 @@ __global__ void h2_bank_max_kernel(const float *__restrict__ w, int Ko, int tran
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(header, __builtin_bit_cast(unsigned, mx));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(header, __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // packed[mblk][chunk][ky][xi][piece][half][l31][e] (fp16) = piece of s (G g)[xi] of kernel row ky of the
@@ -681,7 +727,7 @@ int h2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int tra
     const size_t bank_floats = h2_packed_floats(K, M) - kHeaderFloats;
     unsigned *header = reinterpret_cast<unsigned *>(packed + bank_floats);
     STX_HIP(hipMemsetAsync(header, 0, kHeaderFloats * sizeof(float), s));
-    h2_bank_max_kernel<<<(int)std::min<size_t>(((size_t)M * K * 12 + 255) / 256, 4096), 256, 0, s>>>(
+    h2_bank_max_kernel<<<(int)std::min<size_t>(((size_t)M * K * 12 + 255) / 256, 256), 256, 0, s>>>(
         w_caffe, Ko, transpose_flip, M, K, header);
     STX_CHECK_LAUNCH();
     const size_t total = bank_floats * 2;

@@ -510,11 +510,15 @@ __device__ __forceinline__ float splitk_reduce_element(const SplitReduceArgs &a,
 
 // max |y| of a pass into the slots the next fp16-split convolution reads (conv_h2.hip): one atomic per wave
 __device__ __forceinline__ void splitk_reduce_amax(const SplitReduceArgs &a, float amax) {
-    if (!a.y_amax) return;
+    if (!a.y_amax) return;          // (uniform)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
-    if ((threadIdx.x & 63) == 0)
-        atomicMax(a.y_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kAmaxSlots - 1)), __builtin_bit_cast(unsigned, amax));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(a.y_amax + (blockIdx.x & (kAmaxSlots - 1)),
+                  __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
@@ -707,7 +711,8 @@ static SplitReduceArgs splitk_reduce_args(const ConvProblem &p, int ksplit) {
 int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
     const SplitReduceArgs r = splitk_reduce_args(p, ksplit);
     const size_t n = (size_t)p.M * p.H * p.W;
-    splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, s>>>(r);
+    // (with y_amax every block ends in an atomic on one of kAmaxSlots words: fewer, longer blocks)
+    splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, p.y_amax ? 1024 : 4096), 256, 0, s>>>(r);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }

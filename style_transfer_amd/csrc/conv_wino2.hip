@@ -72,7 +72,7 @@ struct Geo {
 constexpr int U_FLOATS = 4 * KC * BM * 4;     // [xi][ci][m][nu]
 constexpr int V_FLOATS = 4 * KC * 64 * 4;     // [xi][ci][tile][nu]
 constexpr int STAGE = U_FLOATS + V_FLOATS;    // 64 KB
-constexpr size_t kLdsBytes = 2 * STAGE * sizeof(float);
+constexpr size_t kLdsBytes = 2 * STAGE * sizeof(float) + 64;     // + the waves' maxima (y_amax)
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -645,6 +645,10 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                 ccol[e] = r < 0 ? r + cw_cw : r;
             }
         }
+        // max |y| of what this lane stores, for an fp16-split convolution that reads the blob next
+        // (ConvProblem::y_amax; conv_h2.hip)
+        const bool track = EPI != kEpiPartial && a.y_amax != nullptr;
+        float amax = 0.f;
         auto tail = [&](auto even_c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -712,6 +716,9 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             }
                         }
                         o[y] = v;
+                        if (track)
+                            amax = fmaxf(amax, fmaxf(vo[y][0] != kOob ? fabsf(v.x) : 0.f,
+                                                     vo[y][1] != kOob ? fabsf(v.y) : 0.f));
                         if (EPI != kEpiForward || !a.skip_y) st2(ry_c, y, so, v, even_c);
                     }
                     // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
@@ -744,6 +751,18 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         };
         if (weven) tail(yes{});
         else tail(no{});
+        if (track) {          // one atomic per workgroup
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+            float *wmax = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + kLdsBytes - 64);
+            if (lane == 0) wmax[wave] = amax;
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int w = 1; w < 8; ++w) amax = fmaxf(amax, wmax[w]);
+                atomicMax(a.y_amax + (blockIdx.x & (kAmaxSlots - 1)), __builtin_bit_cast(unsigned, amax));
+            }
+        }
     }
 #undef STX_PK_ADD
 #undef STX_PK_SUB
@@ -1029,12 +1048,14 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     // backward kernels; K slices and the BIG variants keep the fp32 mask
     const bool codes = conv_uses_relu_codes(cfg, p, split ? ksplit : 1) && !big;
     a.clock_out = p.clock_out;
+    a.y_amax = p.y_amax;              // (K slices: the reduce pass leaves it, splitk_reduce_args)
     a.in_codes = codes && p.epilogue == kEpiForward ? p.in_codes : nullptr;
     a.mask_codes = codes && p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
     const bool mk = a.mask_codes != nullptr || a.in_codes != nullptr;
     if (split) {
         a.ksplit = ksplit;
         a.y = p.splitk_ws;
+        a.y_amax = nullptr;
         n_wg *= ksplit;
     } else if (p.epilogue == kEpiForward && wino2_fuses_pool(p)) {
         a.pool_out = p.pool_out;
@@ -1083,6 +1104,7 @@ static int wino2_launch_tail(hipStream_t s, const ConvConfig &cfg, const ConvPro
     part.item_base = n_full;
     part.y = p.splitk_ws;
     part.clock_out = nullptr;
+    part.y_amax = nullptr;
 #define STX_W2_TAIL(E)                                                                            \
     case E:                                                                                       \
         STX_TRY(cfg.id == 201   ? (wino2_launch_epi<E, 8>(s, whole, n_full))                      \

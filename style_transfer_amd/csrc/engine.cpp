@@ -518,9 +518,16 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 }
 
 // The fp16-split kernel (conv_h2.hip) for this problem?  Layers with at least STX_CONV_H2 input
-// channels (default 256; 0: never), by shape and epilogue only -- never by timing: it rounds
+// channels (default 128; 0: never), by shape and epilogue only -- never by timing: it rounds
 // differently from the fp32 kernels, and a given shape must always take the same path.
 // STX_CONV_ALGO=h2|h2a|h2b forces it (either / the 64- / the 128-channel tiling) wherever it applies.
+static bool h2_enabled() {
+    const char *algo = getenv("STX_CONV_ALGO");
+    if (algo && *algo) return !strncmp(algo, "h2", 2);
+    const char *env = getenv("STX_CONV_H2");
+    return !env || atoi(env) > 0;
+}
+
 static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
     const char *algo = getenv("STX_CONV_ALGO");
     int force = 0;
@@ -531,7 +538,7 @@ static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
         else return false;             // some other kernel family was asked for
     }
     const char *env = getenv("STX_CONV_H2");
-    const int min_k = env ? atoi(env) : 256;
+    const int min_k = env ? atoi(env) : 128;
     if (!force && (min_k <= 0 || p.K < min_k || p.M < 64)) return false;
     if (!h2_usable(p)) return false;
     *out = force == 1 ? h2_config(1) : force == 2 ? h2_config(2) : h2_pick_config(p);
@@ -600,8 +607,9 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     p.wants_codes = b.relu_codes_wanted;
     if (!h2) STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
     t.amax_data = -1;
-    if (h2) {
-        STX_TRY(amax_for(e, L.bottom_blob, false, &p.x_amax));
+    if (h2) STX_TRY(amax_for(e, L.bottom_blob, false, &p.x_amax));
+    // the eight-wave fp32 kernel leaves its output's maximum too (conv3_1 feeds conv3_2)
+    if (h2 || (cfg.id >= 200 && cfg.id < 210 && h2_enabled())) {
         p.y_amax = e->amax_slots(L.top_blob, false);
         t.amax_data = L.top_blob;          // (a K-sliced launch leaves it through its reduce pass)
     }
@@ -696,6 +704,8 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     if (h2) {
         p.mask_codes = nullptr;
         STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
+    }
+    if (h2 || (cfg.id >= 200 && cfg.id < 210 && h2_enabled())) {
         p.y_amax = e->amax_slots(L.bottom_blob, true);
         b.amax_diff = L.bottom_blob;
     }
