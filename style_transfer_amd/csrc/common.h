@@ -230,7 +230,7 @@ int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int 
 bool conv_first_usable(int K, int M, int ksize);
 int conv_first_workgroups(int H, int W);
 int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const float *bias, float *y,
-                      int K, int H, int W, int relu, float *gram_partials);
+                      int K, int H, int W, int relu, float *gram_partials, unsigned *y_amax = nullptr);
 
 // 2-D Winograd F(2x2,3x3) variant (conv_wino2.hip); config id 200.
 ConvConfig wino2_config(int geometry = 0);     // 0: 4 x 64 pixel patches, 1: 16 x 16, 2: 8 x 32

@@ -61,6 +61,7 @@ struct FirstArgs {
     const float *bias;       // [64] or null
     float *y;                // [64][H][W]
     float *gram;             // GRAM: one 64 x 64 partial tile per workgroup
+    unsigned *y_amax;        // (or null) max |y| as float bits into kAmaxSlots words: ConvProblem::y_amax
     int K, H, W, tiles_x, n_tiles, relu, vec_store, strided;
 };
 
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs
     constexpr unsigned kOobY = 0xfffffff0u;
     const int y_ch0 = tid >> 5, y_c4 = (tid & 31) * 4;
     const unsigned y_voff = (unsigned)(((size_t)y_ch0 * HW + y_c4) * 4);
+    const bool track = a.y_amax != nullptr;      // uniform
+    float amax = 0.f;
     auto segment = [&](int t, int buf, const float (&pin)[kPL], float (&pout)[kPL]) {
         // (past the last segment: every offset out of range, the loads return zeros nobody uses --
         // unconditional, like the stores, so that the memory counter's arithmetic is exact)
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs
                     v.x = 8 * j + 0 < room ? v.x : 0.f, v.y = 8 * j + 1 < room ? v.y : 0.f;
                     v.z = 8 * j + 2 < room ? v.z : 0.f, v.w = 8 * j + 3 < room ? v.w : 0.f;
                 }
+                if (track) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 *reinterpret_cast<f32x4 *>(tile + (mb * 32 + l31) * kFLd + wave * 32 + 8 * j + 4 * half) = v;
             }
         lds_barrier();      // the tile is complete (and everybody has left the previous segment's reads)
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs
         lds_barrier();      // tile reads done; the next patch is in place
     };
 
+    // (the maximum of the blob, for an fp16-split convolution that reads it next: conv_h2.hip)
     // the planes past K of both patch buffers: zero (0 x garbage could be NaN)
     for (int i = tid; i < 2 * kPatch; i += kNT) patch[i] = 0.f;
     lds_barrier();
@@ -294,6 +299,16 @@ __global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs
         if (t + grid < t_end) segment(t + grid, 1, pb2, pa);
     }
 
+    if (track) {          // one atomic per workgroup
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+        lds_barrier();
+        if (lane == 0) lds[wave] = amax;
+        lds_barrier();
+        if (tid == 0)
+            atomicMax(a.y_amax + (blockIdx.x & (kAmaxSlots - 1)),
+                      __builtin_bit_cast(unsigned, fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]))));
+    }
     if (GRAM) {
         // the four waves' tiles added in wave order -- ((w0 + w1) + w2) + w3 per element, as
         // gram_partial_bf3_kernel adds them -- in four rounds through ONE 16 KB tile (all four side by
@@ -348,7 +363,7 @@ static int conv_first_plain_workgroups(int H, int W) {
 // y = [relu](conv(x, w) + bias); gram_partials (or null): conv_first_workgroups(H, W) partial tiles
 // of 64 x 64 floats, to be finished with a GramPlan {C 64, HW, splits = that count, tiles 1}.
 int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const float *bias, float *y,
-                      int K, int H, int W, int relu, float *gram_partials) {
+                      int K, int H, int W, int relu, float *gram_partials, unsigned *y_amax) {
     if (4.0 * K * (double)H * W >= 2147483648.0) {       // (tiles beyond 13 000 x 13 000: the 8192^2 limit
         set_error("conv_first_launch: a %d x %d plane is beyond the buffer-addressing limit", H, W);   // of the
         return STX_ERR_UNSUPPORTED;                       //  other kernels comes first)
@@ -359,6 +374,7 @@ int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const
     a.bias = bias;
     a.y = y;
     a.gram = gram_partials;
+    a.y_amax = y_amax;
     a.K = K;
     a.H = H;
     a.W = W;

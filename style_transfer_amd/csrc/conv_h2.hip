@@ -109,6 +109,10 @@ __device__ __forceinline__ float pow2f(int e) {          // 2^e, e clamped to th
 
 #ifdef STX_H2_TIMING   // cycle counters for tools/ubench/h2conv_bench.hip
 __device__ long long g_h2_timing[8][8];
+__device__ long long g_h2_epi[8][8];     // epilogue, pass 0: loads issued, first barrier, exchange written + barrier, done
+#define STX_H2_STAMP(i) if (pass == 0) t_epi[i] = clock64()
+#else
+#define STX_H2_STAMP(i)
 #endif
 
 template <int EPI, int MB>
@@ -283,6 +287,98 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     for (int b = 0; b < MB; ++b)
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[b][j]));
+    // ---- the epilogue's addresses and descriptors, set up here, under the first loads' latency (a thousand
+    // cycles of scalar and vector work where they stood, between the chunk loop and the first store).
+    // Epilogue: components through LDS, [xi][wh][j][rq][lane] x (registers 4 rq .. 4 rq + 3), one
+    // 32-channel block per wave and pass.  Then wave (hh, m, rqp) finishes pixel blocks (m, 0) and (m, 1)
+    // of channel block hh for register quads 2 rqp, 2 rqp + 1: per lane and channel (D register r of a
+    // block is channel (r & 3) + 8 (r >> 2) + 4 half) the 2 x 2 window at rows y, y + 1, columns x, x + 1.
+    float s_scale = 0.f, c_scale = 0.f;
+    if (EPI == kEpiDgradInject) {
+        const float n = (float)((size_t)a.M * HW);
+        if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
+        if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
+    }
+    const int hh = wave & 1, mrow = (wave >> 1) & 1, rqp = wave >> 2;
+    const bool weven = (a.W & 1) == 0;
+    const int yy = y0 + 4 * mrow + 2 * (l31 >> 4), xx0 = x0 + 2 * (l31 & 15);
+    const unsigned plane_bytes = (unsigned)a.M * HW4;
+    unsigned vo[2][2];                        // [row][column] of the lane's 2 x 2 outputs
+    {
+        const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                vo[y][e] = (yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u : kOob;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.mask), 0, a.mask ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rft = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
+    const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
+        a.pool_codes, 0, a.pool_codes ? a.M * ph * pw : 0, 0x00020000);
+    const unsigned vpool = (yy < a.H && xx0 < a.W)
+                               ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
+                               : kOob;
+    // ReLU sign nibbles of the output blob (ConvProblem::mask_codes): the lane's 2 x 2 outputs are one window
+    const int cph = (a.H + 1) >> 1, cpw = (a.W + 1) >> 1;
+    const __amdgpu_buffer_rsrc_t rmc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(a.mask_codes), 0, a.mask_codes ? a.M * cph * cpw : 0, 0x00020000);
+    const unsigned vmc = (yy < a.H && xx0 < a.W)
+                             ? (unsigned)((4 * half) * cph * cpw + (yy >> 1) * cpw + (xx0 >> 1))
+                             : kOob;
+    const int M_ = a.M;
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, auto even_c) __attribute__((always_inline)) {
+        if (decltype(even_c)::value)
+            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y][0], so, 0));
+        f32x2 v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][0], so, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
+        return v;
+    };
+    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
+                   __attribute__((always_inline)) {
+        if (STX_H2_SKIP & 8) {        // (timing experiment: the epilogue without its stores)
+            if (v.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, vo[y][0], so, 0);
+            return;
+        }
+        if (decltype(even_c)::value) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
+        } else {
+            const float v0 = v.x, v1 = v.y;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, vo[y][1], so, 0);
+        }
+    };
+    const float *const content = a.inj.content;
+    const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
+              cw_ox = a.inj.win.ox - a.inj.win.sx;
+    int crow[2] = {0, 0}, ccol[2] = {0, 0};     // common.h: content_index, once per lane
+    if (EPI == kEpiDgradInject && content) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const bool ok = yy + y < a.H && xx0 < a.W;
+            int r = (cw_oy + (ok ? yy + y : 0)) % cw_ch;
+            crow[y] = (r < 0 ? r + cw_ch : r) * cw_cw;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = yy < a.H && xx0 < a.W;
+            const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
+            int r = (cw_ox + x) % cw_cw;
+            ccol[e] = r < 0 ? r + cw_cw : r;
+        }
+    }
     stage_all(0, 0);
     if (c_begin + 1 < c_end) x_load(0, c_begin + 1);
     if (n_units == 2) {
@@ -383,89 +479,6 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const long long t_end = clock64(), w_end = wall_clock64();
 #endif
 
-    // ---- epilogue.  Components through LDS, [xi][wh][j][rq][lane] x (registers 4 rq .. 4 rq + 3), one
-    // 32-channel block per wave and pass.  Then wave (hh, m, rqp) finishes pixel blocks (m, 0) and (m, 1)
-    // of channel block hh for register quads 2 rqp, 2 rqp + 1: per lane and channel (D register r of a
-    // block is channel (r & 3) + 8 (r >> 2) + 4 half) the 2 x 2 window at rows y, y + 1, columns x, x + 1.
-    float s_scale = 0.f, c_scale = 0.f;
-    if (EPI == kEpiDgradInject) {
-        const float n = (float)((size_t)a.M * HW);
-        if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / n + kEps));
-        if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / n + kEps));
-    }
-    const int hh = wave & 1, mrow = (wave >> 1) & 1, rqp = wave >> 2;
-    const bool weven = (a.W & 1) == 0;
-    const int yy = y0 + 4 * mrow + 2 * (l31 >> 4), xx0 = x0 + 2 * (l31 & 15);
-    const unsigned plane_bytes = (unsigned)a.M * HW4;
-    unsigned vo[2][2];                        // [row][column] of the lane's 2 x 2 outputs
-    {
-        const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                vo[y][e] = (yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u : kOob;
-    }
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.mask), 0, a.mask ? (int)plane_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.inj.sgrad), 0, a.inj.sgrad ? (int)plane_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rft = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
-    const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
-    const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
-        a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
-        a.pool_codes, 0, a.pool_codes ? a.M * ph * pw : 0, 0x00020000);
-    const unsigned vpool = (yy < a.H && xx0 < a.W)
-                               ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
-                               : kOob;
-    const int M_ = a.M;
-    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, auto even_c) __attribute__((always_inline)) {
-        if (decltype(even_c)::value)
-            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y][0], so, 0));
-        f32x2 v;
-        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][0], so, 0));
-        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
-        return v;
-    };
-    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
-                   __attribute__((always_inline)) {
-        if (STX_H2_SKIP & 8) {        // (timing experiment: the epilogue without its stores)
-            if (v.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, vo[y][0], so, 0);
-            return;
-        }
-        if (decltype(even_c)::value) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
-        } else {
-            const float v0 = v.x, v1 = v.y;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, vo[y][0], so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, vo[y][1], so, 0);
-        }
-    };
-    const float *const content = a.inj.content;
-    const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
-              cw_ox = a.inj.win.ox - a.inj.win.sx;
-    int crow[2] = {0, 0}, ccol[2] = {0, 0};     // common.h: content_index, once per lane
-    if (EPI == kEpiDgradInject && content) {
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const bool ok = yy + y < a.H && xx0 < a.W;
-            int r = (cw_oy + (ok ? yy + y : 0)) % cw_ch;
-            crow[y] = (r < 0 ? r + cw_ch : r) * cw_cw;
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const bool ok = yy < a.H && xx0 < a.W;
-            const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
-            int r = (cw_ox + x) % cw_cw;
-            ccol[e] = r < 0 ? r + cw_cw : r;
-        }
-    }
     float amax = 0.f;                          // max |y| over what this lane stores
     f32x4 *ex = reinterpret_cast<f32x4 *>(ldsb);
 
@@ -474,6 +487,9 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // want at the same moment) is requested BEFORE the exchange and lands during it -- read where it
     // is used, every one of the sixteen loads of a lane exposed its full latency: 28 k cycles per
     // epilogue of two passes instead of 12 k.
+#ifdef STX_H2_TIMING
+    long long t_epi[4] = {0, 0, 0, 0};
+#endif
     auto epilogue_pass = [&](auto pass_c, auto even_c) __attribute__((always_inline)) {
         constexpr int pass = decltype(pass_c)::value;
         const int cblk = m0 + (hh * MB + pass) * 32;
@@ -483,6 +499,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         };
         float bs[8];
         f32x2 mk[16], sg[16];
+        unsigned mkb[8];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
             const int c = chan(n);
@@ -492,14 +509,17 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                                                                rbias, (unsigned)half * 16u, (unsigned)c * 4u, 0))
                                : 0.f;
             } else if (EPI != kEpiPartial) {
+                if (a.mask_codes) mkb[n] = __builtin_amdgcn_raw_buffer_load_b8(rmc, vmc, (unsigned)(c * cph * cpw), 0);
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
-                    if (a.mask && !(STX_H2_SKIP & 16)) mk[2 * n + y] = ld2(rmask, y, so, even_c);
+                    if (!a.mask_codes && a.mask && !(STX_H2_SKIP & 16)) mk[2 * n + y] = ld2(rmask, y, so, even_c);
                     if (EPI == kEpiDgradInject && a.inj.sgrad) sg[2 * n + y] = ld2(rsg, y, so, even_c);
                 }
             }
         }
+        STX_H2_STAMP(0);
         __syncthreads();          // the last B reads (pass 0) / the previous pass's reads are done
+        STX_H2_STAMP(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -508,6 +528,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                     f32x4{acc[pass][j][4 * rq], acc[pass][j][4 * rq + 1], acc[pass][j][4 * rq + 2],
                           acc[pass][j][4 * rq + 3]};
         __syncthreads();
+        STX_H2_STAMP(2);
 #pragma unroll
         for (int rqi = 0; rqi < 2; ++rqi) {
             const int rq = 2 * rqp + rqi;
@@ -540,7 +561,11 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 } else if (EPI != kEpiPartial) {
 #pragma unroll
                     for (int y = 0; y < 2; ++y) {
-                        if (a.mask && !(STX_H2_SKIP & 16)) {
+                        if (a.mask_codes) {
+                            const unsigned nib = mkb[n] >> (2 * y);
+                            v[y].x = (nib & 1u) ? v[y].x : 0.f;
+                            v[y].y = (nib & 2u) ? v[y].y : 0.f;
+                        } else if (a.mask && !(STX_H2_SKIP & 16)) {
                             v[y].x = mk[2 * n + y].x > 0.f ? v[y].x : 0.f;
                             v[y].y = mk[2 * n + y].y > 0.f ? v[y].y : 0.f;
                         }
@@ -593,8 +618,10 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         }
     };
     static_for<0, MB>([&](auto pass_c) __attribute__((always_inline)) {
+        [[maybe_unused]] constexpr int pass = decltype(pass_c)::value;
         if (weven) epilogue_pass(pass_c, yes{});
         else epilogue_pass(pass_c, no{});
+        STX_H2_STAMP(3);
     });
     // max |y| of this launch's output, for the kernel that reads it next: one atomic per workgroup
     // (thousands of atomics on a few words take longer than the kernel's last round)
@@ -616,6 +643,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         g_h2_timing[wave][2] = clock64() - t_end;
         g_h2_timing[wave][3] = w_loop - w_start, g_h2_timing[wave][4] = w_end - w_loop;
         g_h2_timing[wave][5] = wall_clock64() - w_end;
+        for (int i = 0; i < 4; ++i) g_h2_epi[wave][i] = t_epi[i] - t_end;
     }
 #endif
 }
@@ -754,7 +782,8 @@ ConvConfig h2_config(int mb) {
 bool h2_usable(const ConvProblem &p) {
     if (p.ksize != 3 || p.K % (2 * KC) != 0 || p.K < 2 * KC) return false;
     if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return false;
-    if (p.wants_codes || p.in_codes || p.mask_codes) return false;
+    // (it reads ReLU sign nibbles in place of the fp32 mask; it does not write them)
+    if (p.epilogue == kEpiForward && (p.wants_codes || p.in_codes)) return false;
     const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
     const double wb = 4.0 * (double)h2_packed_floats(p.K, p.M);
     return xb < 2147483648.0 && yb < 2147483648.0 && wb < 2147483648.0;
@@ -849,6 +878,7 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
     a.clock_out = p.clock_out;
     a.x_amax = p.x_amax;
     a.y_amax = p.y_amax;
+    a.mask_codes = p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
     const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
     int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
     const bool split = ksplit > 1 && p.splitk_ws && p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
@@ -856,6 +886,7 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
         a.ksplit = ksplit;
         a.y = p.splitk_ws;
         a.y_amax = nullptr;
+        a.mask_codes = nullptr;        // (the reduce pass masks, from the fp32 blob)
         n_wg *= ksplit;
     } else if (h2_fuses_pool(p)) {
         a.pool_out = p.pool_out;

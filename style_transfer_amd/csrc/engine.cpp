@@ -517,15 +517,21 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
     return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
 }
 
-// The fp16-split kernel (conv_h2.hip) for this problem?  Layers with at least STX_CONV_H2 input
-// channels (default 128; 0: never), by shape and epilogue only -- never by timing: it rounds
-// differently from the fp32 kernels, and a given shape must always take the same path.
-// STX_CONV_ALGO=h2|h2a|h2b forces it (either / the 64- / the 128-channel tiling) wherever it applies.
+// The fp16-split kernel (conv_h2.hip) for this problem?  By shape and epilogue only -- never by timing:
+// it rounds differently from the fp32 kernels, and a given shape must always take the same path.
+//   forward: layers with at least STX_CONV_H2 input channels (default 128; 0: never);
+//   backward: at least STX_CONV_H2_BWD channels of incoming gradient (default 64).
+// Why two thresholds: a forward blob that differs in its last bits flips ReLU / max-pooling near-ties, and
+// the two 64-channel layers hold most of a tile's decisions -- with them on this kernel every bound of
+// tests/ holds except the reference's L-BFGS trajectory of BASELINE config 4 in miniature, which leaves
+// its 2e-4 band at the second step (5.7e-4: the line search amplifies one flip).
+// The backward pass decides nothing: its rounding moves the gradient by 1e-7 and no further.
+// STX_CONV_ALGO=h2|h2a|h2b forces the kernel (either / the 64- / the 128-channel tiling) wherever it applies.
 static bool h2_enabled() {
     const char *algo = getenv("STX_CONV_ALGO");
     if (algo && *algo) return !strncmp(algo, "h2", 2);
-    const char *env = getenv("STX_CONV_H2");
-    return !env || atoi(env) > 0;
+    const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
+    return !env || atoi(env) > 0 || !envb || atoi(envb) > 0;
 }
 
 static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
@@ -537,8 +543,9 @@ static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
         else if (!strcmp(algo, "h2b")) force = 2;
         else return false;             // some other kernel family was asked for
     }
-    const char *env = getenv("STX_CONV_H2");
-    const int min_k = env ? atoi(env) : 128;
+    const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
+    const int min_k = p.epilogue == kEpiForward ? (env ? atoi(env) : 128)
+                                                : (envb ? atoi(envb) : env && atoi(env) <= 0 ? 0 : 64);
     if (!force && (min_k <= 0 || p.K < min_k || p.M < 64)) return false;
     if (!h2_usable(p)) return false;
     *out = force == 1 ? h2_config(1) : force == 2 ? h2_config(2) : h2_pick_config(p);
@@ -584,7 +591,12 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         if (pooled) *pooled = false;
         b.relu_codes_valid = false;
         b.relu_codes_wanted = false;
+        unsigned *y_amax = nullptr;
         t.amax_data = -1;
+        if (h2_enabled()) {
+            y_amax = e->amax_slots(L.top_blob, false);
+            t.amax_data = L.top_blob;
+        }
         float *gram = nullptr;
         if (L.top_blob == e->first_gram_blob) {
             const int parts = conv_first_workgroups(b.h, b.w);
@@ -598,7 +610,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         const double direct = conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks);
         e->flop_algorithmic += direct;
         e->flop_issued += direct;
-        return conv_first_launch(e->stream, p.x, cp.w.f(), cp.b.f(), p.y, cp.cin, b.h, b.w, p.relu, gram);
+        return conv_first_launch(e->stream, p.x, cp.w.f(), cp.b.f(), p.y, cp.cin, b.h, b.w, p.relu, gram, y_amax);
     }
     ConvConfig cfg;
     // the fp16-split kernel where it applies (it neither writes nor reads ReLU nibbles)
@@ -695,16 +707,13 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
         return conv_small_launch(e->stream, p.x, it->second->f(), p.y, p.mask, p.K, p.M, p.H, p.W);
     }
     ConvConfig cfg;
-    const bool h2 = !p.wants_codes && h2_choice(p, &cfg);
+    const bool h2 = h2_choice(p, &cfg);      // (it reads the ReLU nibbles as the eight-wave fp32 kernel does)
     if (!h2) STX_TRY(choose_conv_config(e, li, 1, p, &cfg, inj != nullptr));   // tuned without the injection terms
     const bool can_fuse = cfg.id != 3 && cfg.id != 4 && cfg.id != 8;   // Winograd ids fuse too  // those two have no injecting epilogue
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
     b.amax_diff = -1;
-    if (h2) {
-        p.mask_codes = nullptr;
-        STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
-    }
+    if (h2) STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
     if (h2 || (cfg.id >= 200 && cfg.id < 210 && h2_enabled())) {
         p.y_amax = e->amax_slots(L.bottom_blob, true);
         b.amax_diff = L.bottom_blob;

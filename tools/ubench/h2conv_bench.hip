@@ -172,6 +172,10 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
         printf("   wave %d: prologue %6lld  chunk loop %7lld (%.0f per chunk)  epilogue %6lld cycles;  wall %.2f / %.2f / %.2f us (loop at %.0f MHz)\n",
                wv, t[wv][0], t[wv][1], (double)t[wv][1] / (K / 16), t[wv][2], t[wv][3] / 100.0, t[wv][4] / 100.0,
                t[wv][5] / 100.0, (double)t[wv][1] / (t[wv][4] / 100.0));
+    long long te[8][8];
+    hipMemcpyFromSymbol(te, HIP_SYMBOL(stx::g_h2_epi), sizeof(te));
+    printf("   epilogue pass 0, cycles after the loop: loads issued %lld, through the first barrier %lld, exchange written + barrier %lld, pass done %lld\n",
+           te[0][0], te[0][1], te[0][2], te[0][3]);
 #endif
     hipFree(x), hipFree(y), hipFree(w), hipFree(packed), hipFree(bias), hipFree(chans), hipFree(ref);
     hipFree(mask), hipFree(amax);
