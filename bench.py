@@ -34,10 +34,11 @@ bit; a run on real xGMI thereby validates the peer copies / RCCL transfers by it
 
 The line also carries
   roofline      the time the kernels' own instructions need on the matrix pipe, in fp32-MFMA FLOP,
-                for the concurrent tile-iterations of one GPU (convolutions through Winograd
-                F(2x2,3x3) issue 4/9 of a direct convolution's MFMAs; Gram and SYMM run as six bf16
-                MFMAs per 16 k and are counted at the 0.375 of their fp32 pipe time that this
-                occupies) over the GPU time of that concurrent group of stx_sc_grad_tile calls --
+                for the concurrent tile-iterations of one GPU (fp32 convolutions through Winograd
+                F(2x2,3x3) issue 4/9 of a direct convolution's MFMAs; the fp16-split convolutions,
+                1-D Winograd F(2,3) with three fp16 MFMAs of 1/16 of an fp32 MFMA's time per k,
+                6/9 x 3/16 = 1/8 of it; Gram and SYMM run as six bf16 MFMAs per 16 k and are
+                counted at the 0.375 of their fp32 pipe time that this occupies) over the GPU time of that concurrent group of stx_sc_grad_tile calls --
                 HIP events on each engine's own stream inside the timed region, the longest of the
                 spans -- against the fp32 MFMA peak, so that frac <= 1 by construction;
                 `frac_driver_clock` divides the same work by the wall-clock ms_per_step instead;
@@ -67,6 +68,11 @@ TILE = 1024
 FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
 NOMINAL_CLOCK_MHZ = 2400.0
+# the arithmetic the path computes in: float32 values throughout; the 3x3 layers from 128 channels up
+# form their products on the fp16 matrix cores from two-piece operands (22 significand bits) and add
+# them in fp32 -- every parity bound of tests/ is the float32 kernels' own (STX_CONV_H2=0: fp32 MFMAs only)
+DTYPE = ('f32' if os.environ.get('STX_CONV_H2') == '0' and not os.environ.get('STX_CONV_H2_BWD')
+         else 'f32 (fp16x2-split MFMA, fp32 accumulate)')
 STREAMS_PER_GPU = 4                    # engines (HIP streams) a GPU runs its tiles of a step on
 STRONG_GRID = (2, 2)                   # BASELINE's metric: --size 2048 --tile-size 1024
 CONFIG4_GRID = (4, 4)                  # BASELINE config 4's top scale: --size 4096, 16 tiles
@@ -408,9 +414,11 @@ def add_clock(roofline, clock):
 def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
     """Matrix-pipe work of one GPU's concurrent tile evaluations over their HIP-event span,
     against the fp32 MFMA peak.  Every term is the time the kernels' own instructions need on the
-    matrix pipe, expressed in fp32-MFMA FLOP: Winograd convolutions issue 4/9 (2-D) or 2/3 (1-D) of
-    a direct convolution's fp32 MFMAs; Gram and SYMM issue six bf16 MFMAs per 16 k, which occupy
-    the pipe for 0.375 of the time their fp32 form would -- so frac <= 1 by construction."""
+    matrix pipe, expressed in fp32-MFMA FLOP: fp32 Winograd convolutions issue 4/9 (2-D) or 2/3 (1-D)
+    of a direct convolution's fp32 MFMAs; the fp16-split convolutions (conv_h2.hip) three fp16 MFMAs
+    per 16 k for 6 of every 9 multiplies, i.e. 1/8 of a direct convolution's fp32 pipe time; Gram and
+    SYMM issue six bf16 MFMAs per 16 k, which occupy the pipe for 0.375 of the time their fp32 form
+    would -- so frac <= 1 by construction."""
     flop = FLOP_PER_TILE_PIXEL * TILE * TILE * tiles_per_gpu
     direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
     conv_alg, conv_issued = eng.last_tile_flops()
@@ -431,27 +439,32 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
             'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / tiles_per_gpu,
             'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
-            'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_wino2_kernel<0|1|3,32> '
-                      '(3x3 layers forward / backward / loss-injecting backward; 80 %% of the time), '
-                      'conv_mfma_kernel (first layer), conv3x3_m4_kernel (backward into the image), '
-                      'gram_partial_bf3_kernel / symm_bf3_kernel (bf16 MFMA, three-piece split)'
-                      % tiles_per_gpu,
+            'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_h2_kernel<0|1|3,2> (3x3 layers '
+                      'from 128 input channels forward, from 64 backward: fp16 MFMA, two-piece operand '
+                      'split, fp32 accumulate; forward / backward / loss-injecting backward; half of the '
+                      'time), conv_wino2_kernel<0|3,32> (the 64-channel layers forward, conv1_2 backward: '
+                      'fp32 MFMA), conv_first_kernel (first layer + its Gram partials), conv3x3_m4_kernel '
+                      '(backward into the image), gram_partial_bf3_kernel / symm_bf3_kernel (bf16 MFMA, '
+                      'three-piece split)' % tiles_per_gpu,
             'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
             'achieved_direct_equiv': direct_equiv,
             'flop_direct_equiv_per_launch': flop,
-            'note': 'achieved / frac = matrix-pipe work actually issued, in fp32-MFMA FLOP (Winograd '
-                    'F(2x2,3x3) convolutions issue 4/9 of a direct convolution; Gram and SYMM run as '
-                    'six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 form and are '
-                    'counted at that) over the HIP-event time of the launch group, against the fp32 '
-                    'MFMA peak at 2.4 GHz; frac_driver_clock = the same work over the wall-clock '
-                    'ms_per_step; clock_mhz is the shader clock INSIDE the 2-D Winograd convolution '
-                    'kernels during the second, longer measurement (`steady`; stx_clock_marks: one '
+            'note': 'achieved / frac = the time the issued matrix instructions need on the matrix pipe, '
+                    'priced in fp32-MFMA FLOP (fp32 Winograd F(2x2,3x3) convolutions issue 4/9 of a direct '
+                    'convolution; the fp16-split 1-D Winograd convolutions three fp16 MFMAs of 1/16 of an '
+                    'fp32 MFMA\'s time per k for 6 of 9 multiplies = 1/8 of a direct convolution\'s pipe '
+                    'time; Gram and SYMM six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 '
+                    'form) over the HIP-event time of the launch group, against the fp32 '
+                    'MFMA peak at 2.4 GHz: the fraction of that time the matrix pipes are busy at the '
+                    'nominal clock; frac_driver_clock = the same work over the wall-clock '
+                    'ms_per_step; clock_mhz is the shader clock INSIDE the Winograd convolution '
+                    'kernels (fp32 and fp16-split) during the second, longer measurement (`steady`; stx_clock_marks: one '
                     'workgroup of every launch reads core cycles and the 100 MHz counter around its '
                     'chunk loop; the median over the launches, with the 10th / 90th percentile), '
                     'peak_at_clock the fp32 MFMA peak at min(that clock, 2.4 GHz) and frac_at_clock = '
-                    'achieved / peak_at_clock: the part is power-limited under fp32 MFMA load and does '
-                    'not hold its 2.4 GHz there (round 3 read the clock between the heavy kernels and '
-                    'saw 2.43 GHz); '
+                    'achieved / peak_at_clock: the part is power-limited under matrix load -- 1.4-1.7 GHz '
+                    'inside the fp16-split kernels, 1.9-2.2 GHz inside the fp32 ones -- and does not hold '
+                    'its 2.4 GHz there; '
                     'frac_round2_accounting counts Gram and SYMM in full as '
                     'round 2 did (they ran on the fp32 pipe then); achieved_direct_equiv credits '
                     'every convolution as a direct one (SURVEY 8d: 1 514 240 FLOP per tile pixel) '
@@ -555,7 +568,7 @@ def base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms, scali
         'unit': 'tile-iterations/s',
         'n_gpus': world, 'steps': opts.steps, 'warmup': opts.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': scaling,
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': DTYPE, 'data': 'synthetic',
         'config': {'workload': 'VGG-19 --size %d --tile-size %d -o adam: %dx%d image, %d tiles of '
                                '%dx%d per step, %d per busy GPU%s'
                                % (max(H, W), TILE, W, H, tiles_per_step, TILE, TILE, tiles_per_gpu,

@@ -146,6 +146,7 @@ class Net:
         self._layer_names = [l['name'] for l in self.layers]
         self.blobs = {}
         self._aux = {}
+        self._split, self._split_pending = {}, set()     # see _split_consumers
         inp = self.layers[0]
         assert inp['type'] == 'Input'
         self.blobs[inp['top']] = Blob(tuple(inp['shape']))
@@ -204,6 +205,16 @@ class Net:
                                         lay['kernel_size'], lay['stride'])
                 self._aux[lay['name']] = aux
 
+    def _split_consumers(self, blob):
+        """Layers that read `blob` without writing it back, if there is more than one: Caffe puts a
+        Split layer behind such a blob (net.cpp: InsertSplits) -- every consumer gets a top of its
+        own, and on the way back the split ADDS the consumers' diffs into the blob's.  The
+        reference's *_big prototxts need it: conv1_2 feeds pool1 (a dead end) and conv2_1
+        (vgg19_big.prototxt:62); without the split the later-run pooling layer would overwrite
+        conv2_1's gradient with its own zeros."""
+        users = [l['name'] for l in self.layers[1:] if l['bottom'] == blob and l['top'] != blob]
+        return users if len(users) > 1 else []
+
     def backward(self, start=None, end=None):
         """Runs layers start..end in reverse (both inclusive, start is the later layer)."""
         i1, i0 = self._index(start, len(self.layers) - 1), self._index(end, 0)
@@ -212,15 +223,28 @@ class Net:
             if t == 'Input':
                 continue
             bottom, top = self.blobs[lay['bottom']], self.blobs[lay['top']]
+            # the Split layer behind a blob with several consumers runs (in reverse order) before
+            # the first layer that wrote the blob: diff = sum of what the consumers left
+            if lay['top'] in self._split_pending:
+                users = self._split_consumers(lay['top'])
+                top.diff[...] = sum(self._split.get((lay['top'], u), 0) for u in users)
+                self._split_pending.discard(lay['top'])
             if t == 'Convolution':
                 w, _ = self.params[lay['name']]
-                bottom.diff[0] = L.conv_backward_data(top.diff[0], w, lay['pad'])
+                d = L.conv_backward_data(top.diff[0], w, lay['pad'])
             elif t == 'ReLU':
                 bottom.diff[...] = top.diff * (bottom.data > 0)
+                continue
             elif t == 'Pooling':
-                bottom.diff[0] = L.pool_backward(top.diff[0], bottom.data.shape[1:],
-                                                 self._aux[lay['name']], lay['pool'],
-                                                 lay['kernel_size'], lay['stride'])
+                d = L.pool_backward(top.diff[0], bottom.data.shape[1:], self._aux[lay['name']],
+                                    lay['pool'], lay['kernel_size'], lay['stride'])
+            else:
+                continue
+            if self._split_consumers(lay['bottom']):
+                self._split[(lay['bottom'], lay['name'])] = d.copy()
+                self._split_pending.add(lay['bottom'])
+            else:
+                bottom.diff[0] = d
 
 
 # pycaffe module-level functions the reference calls in its worker (style_transfer.py:198-203)

@@ -149,6 +149,7 @@ struct stx_engine {
     static constexpr int kTimed = 4;
     hipEvent_t ev_start[kTimed] = {}, ev_stop[kTimed] = {};
     int ev_cur = 0;
+    int ev_recorded = 0;               // ring slots that hold a recorded pair (at most kTimed)
     hipEvent_t ev_tune0 = nullptr, ev_tune1 = nullptr;
     bool timed = false;
     double flop_algorithmic = 0, flop_issued = 0;   // matrix work of the current / last tile call
@@ -865,6 +866,7 @@ int begin_timing(stx_engine *e) {
 
 int end_timing(stx_engine *e) {
     STX_HIP(hipEventRecord(e->ev_stop[e->ev_cur], e->stream));
+    if (e->ev_recorded < stx_engine::kTimed) ++e->ev_recorded;
     e->timed = true;
     return STX_OK;
 }
@@ -2288,15 +2290,17 @@ int stx_last_tile_ms(stx_engine *e, float *ms) {
     }
     STX_TRY(e->set_device());
     // the newest call that has finished; if none of the last few has, wait for the newest
+    // (only slots that were recorded: hipEventQuery calls a never-recorded event complete, and
+    // hipEventElapsedTime then fails on it)
     int pick = e->ev_cur;
-    for (int k = 0; k < stx_engine::kTimed; ++k) {
+    for (int k = 0; k < e->ev_recorded; ++k) {
         const int i = (e->ev_cur - k + stx_engine::kTimed) % stx_engine::kTimed;
         const hipError_t q = hipEventQuery(e->ev_stop[i]);
         if (q == hipSuccess) {
             pick = i;
             break;
         }
-        (void)hipGetLastError();      // hipErrorNotReady (or an event never recorded)
+        (void)hipGetLastError();      // hipErrorNotReady
     }
     STX_HIP(hipEventSynchronize(e->ev_stop[pick]));
     STX_HIP(hipEventElapsedTime(ms, e->ev_start[pick], e->ev_stop[pick]));

@@ -219,7 +219,12 @@ def broadcast_targets(contents, styles, device, group=None):
     """Broadcasts rank 0's targets (lists of {layer: array}) to every rank, once per scale.
     Sources may be numpy arrays, torch tensors or DeviceArrays (``__cuda_array_interface__``:
     broadcast in place on RCCL; ``.get()`` on the gloo debug wire); the result is lists of
-    {layer: torch tensor on ``device``} -- the maps stay on the GPU."""
+    {layer: torch tensor on ``device``} -- the maps stay on the GPU.
+
+    Ownership: on rank 0 a tensor made from a DeviceArray IS that array's memory (no copy: the
+    broadcast reads it where it lies), so the caller keeps the DeviceArray alive for as long as it
+    uses the returned tensor -- `DeviceArray.free()` / `StyleTransfer._drop_contents()` end both.
+    The other ranks get allocations of their own."""
     rank = dist.get_rank(group)
     wire = _wire_device(device, group)
     meta = [None]
@@ -240,6 +245,9 @@ def broadcast_targets(contents, styles, device, group=None):
                         t = v.to(wire, torch.float32).contiguous()
                     elif hasattr(v, '__cuda_array_interface__') and wire.type == 'cuda':
                         # a DeviceArray on this rank's GPU: broadcast it from where it lies
+                        if getattr(v, 'dtype', np.float32) != np.float32 or v.engine.device != (wire.index or 0):
+                            raise ValueError('broadcast_targets: a float32 DeviceArray on this rank\'s GPU '
+                                             'is expected for layer %s' % layer)
                         v.engine.sync()             # (written on the engine's stream, read on torch's)
                         t = torch.as_tensor(v, device=wire)
                     else:

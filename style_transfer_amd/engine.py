@@ -183,16 +183,21 @@ class TileEngine:
     def sync(self):
         lib.call('stx_sync', self.handle)
         self._results = []
+        self._fence_marks = {}
+        self._dropped = 0
 
     def keep_until_sync(self, result):
         """Holds a reference to an object the library will write into at the next sync (a
         pending loss): it must not be collected before, even if its owner lets go of it.  The
         library publishes pending values whenever it drains its scalar arena, also inside calls
-        that never come back through ``sync()``; the list is bounded so that such callers cannot
-        grow it without limit (an entry older than 4096 evaluations has long been published)."""
+        that never come back through ``sync()``.  Entries are dropped when their values have been
+        published: at ``sync()`` and at ``wait_fence()`` (everything queued before that fence).  The
+        count below is a backstop for callers that never do either -- the library drains its arena
+        every few hundred evaluations, so an entry 32768 evaluations old has long been written."""
         self._results.append(result)
-        if len(self._results) > 4096:
-            del self._results[:2048]
+        if len(self._results) > 65536:
+            del self._results[:32768]
+            self._dropped = getattr(self, '_dropped', 0) + 32768
         return result
 
     def fence(self):
@@ -201,11 +206,21 @@ class TileEngine:
         one's losses afterwards, without waiting for the newer work."""
         ticket = ctypes.c_ulonglong(0)
         lib.call('stx_fence', self.handle, ctypes.byref(ticket))
+        if not hasattr(self, '_fence_marks'):
+            self._fence_marks, self._dropped = {}, 0
+        self._fence_marks[ticket.value] = self._dropped + len(self._results)
         return ticket.value
 
     def wait_fence(self, ticket):
-        """Waits for the fence's event only and publishes the values it closed."""
+        """Waits for the fence's event only and publishes the values it closed; the objects
+        those values were written into are released from ``keep_until_sync``."""
         lib.call('stx_fence_wait', self.handle, int(ticket))
+        mark = getattr(self, '_fence_marks', {}).pop(int(ticket), None)
+        if mark is not None:
+            n = mark - self._dropped
+            if n > 0:
+                del self._results[:n]
+                self._dropped += n
 
     def wait_for(self, other):
         """Orders this engine's stream behind what ``other`` has queued so far (no host wait)."""

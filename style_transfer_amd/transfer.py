@@ -142,7 +142,8 @@ class StyleTransfer:
         self.current_raw = None     # DeviceArray: averaged iterate of the last step
         self.step = 0
         self.step_times = []
-        self.steps_queued = 0       # iterations queued so far in this run (all scales)
+        # calls made to the callback object at hand (transfer's run-ahead loop asks it about its n-th call)
+        self._cb_calls = [None, 0]
         self._converted = {}        # id(PIL image) -> (image, float array), filled by the helper thread
         # --swt-weight (style_transfer.py:716-720) calls PyWavelets, which is not part of the
         # reference tree; its transform is restated for the command line's defaults only
@@ -306,6 +307,11 @@ class StyleTransfer:
                      (callback is None or hasattr(callback, 'wants_image')))
         in_flight = []
         t_prev = [time.perf_counter()]
+        # `wants_image(n)` is asked about the n-th call THIS callback object gets (1-based, over all
+        # scales of all runs it is passed to through this StyleTransfer): counted per object, so that
+        # a fresh callback on a reused StyleTransfer starts at 1 again
+        if self._cb_calls[0] is not callback:
+            self._cb_calls = [callback, 0]
 
         def finish(item):
             step_i, loss_i, stats_i = item
@@ -314,10 +320,29 @@ class StyleTransfer:
             now = time.perf_counter()
             self.step_times.append(now - t_prev[0])
             t_prev[0] = now
+            self._cb_calls[1] += 1
             if callback is not None:
                 callback(step=step_i, update_size=update_size, loss=loss_v, tv_loss=tv_loss,
                          transfer=self)
 
+        try:
+            self._step_loop(iterations, callback, run_ahead, in_flight, finish, jitter, jitter_scale,
+                            img_size, state, content_images, content_layers, style_layers,
+                            content_weight, style_weight, dd_layers, dd_weight)
+        finally:
+            # an interrupt or an error in iteration i + 1 must not lose the finished iteration i
+            # (its statistics row, its --save-every picture)
+            while in_flight:
+                item = in_flight.pop(0)
+                try:
+                    finish(item)
+                except Exception:       # (the device may be the thing that failed)
+                    break
+        return self.current_raw
+
+    def _step_loop(self, iterations, callback, run_ahead, in_flight, finish, jitter, jitter_scale, img_size,
+                   state, content_images, content_layers, style_layers, content_weight, style_weight,
+                   dd_layers, dd_weight):
         for step in range(1, iterations + 1):
             t0 = time.perf_counter()
             state.step = step - 1
@@ -339,7 +364,6 @@ class StyleTransfer:
                        dd_layers, dd_weight, content_roll)
             avg_img, loss = self.optimizer.update(lambda p: self.eval_loss_and_grad(p, sc_args))
             self.optimizer.roll(-roll)
-            self.steps_queued += 1
             if run_ahead:
                 stats = image_ops.step_stats_async(self.engine, avg_img, self.old_avg)
                 loss.seal(also=[self.engine])
@@ -350,17 +374,17 @@ class StyleTransfer:
                 # a callback that will look at this step's image gets it before the next step
                 # overwrites it
                 if step == iterations or (callback is not None and
-                                          callback.wants_image(self.steps_queued)):
+                                          callback.wants_image(self._cb_calls[1] + len(in_flight))):
                     finish(in_flight.pop())
                 continue
             update_size, tv_loss = image_ops.step_stats(self.engine, avg_img, self.old_avg)
             loss = float(loss)              # (everything is finished by now: publishes the terms)
             self.current_raw = avg_img
             self.step_times.append(time.perf_counter() - t0)
+            self._cb_calls[1] += 1
             if callback is not None:
                 callback(step=step, update_size=update_size, loss=loss, tv_loss=tv_loss,
                          transfer=self)
-        return self.current_raw
 
     # ------------------------------------------------------------------------- all scales
     def _first_iterate(self, plan, initial_image):

@@ -54,6 +54,8 @@ TILE_CASES = [
     (724, 724, 1448, 1448, (724, 724), (64, -128)),
     (965, 966, 2896, 2896, (1930, 965), (-8, 1024)),
     (2048, 2048, 2048, 2048, (0, 0), (-1000, 344)),
+    # SURVEY section 7's odd size: 543 -> 272 -> 136 -> 68 -> 34, odd planes at the top, even below
+    (543, 543, 1086, 1086, (543, 0), (40, -72)),
 ]
 # Two float32 forward passes that agree to ~1e-6 still decide a few ReLU signs / pooling winners
 # differently (37 + 29 of 1.5e8 decisions on the 1024^2 tile); each flip taints the image pixels

@@ -109,6 +109,33 @@ def test_sc_grad_tile_odd_sizes_against_oracle(model, th, tw):
                flip_l2=1e-3 if 'avg' in model and th * tw > 400 else FLIP_L2)
 
 
+@pytest.mark.parametrize('model', ['vgg19_big', 'vgg16_big'])
+@pytest.mark.parametrize('th,tw', [(45, 61), (66, 50)])
+def test_big_nets_whose_second_stage_skips_the_first_pooling(model, th, tw):
+    """The reference's *_big prototxts (vgg19_big.prototxt:62) feed conv2_1 from conv1_2: pool1 is a
+    dead end, every plane from conv2_x down is twice as wide and high as in the plain net, the
+    content map is a quarter of the image per side.  Tile path (activations of every blob, loss,
+    gradient) and feature maps -- including the dead-end pool1 -- against the oracle."""
+    om, _ = make_oracle(model)
+    eng = gpu_engine(model)
+    rng = np.random.RandomState(th)
+    cl, cw = normalized_weights(['conv4_2'], 0.05)
+    sl, sw = normalized_weights(DEFAULT_STYLE_LAYERS, 1)
+    full = rng.uniform(-110, 120, (3, th + 24, tw + 40)).astype(np.float32)
+    style = rng.uniform(-110, 120, (3, 50, 60)).astype(np.float32)
+    om.styles = [om.style_grams([style], sl, 512)]
+    om.contents = [om.prepare_features(full, cl, 512)]
+    assert om.contents[0]['conv4_2'].shape[1:] == (-(-(th + 24) // 4), -(-(tw + 40) // 4))
+    eng.set_contents_and_styles(om.contents, om.styles)
+    tile = np.ascontiguousarray(full[:, 16:16 + th, 8:8 + tw])
+    check_tile(eng, om, tile, (16, 8), (-16, 24), cl, cw, sl, sw, {})
+    wanted = ['pool1', 'conv2_1', 'conv5_1']
+    feats, ref = eng.features_tile(tile, wanted), om.features_tile(tile, wanted)
+    assert feats['conv2_1'].shape[1:] == (th, tw) and feats['pool1'].shape[1:] == (-(-th // 2), -(-tw // 2))
+    for l in wanted:
+        assert max_rel(feats[l], ref[l]) < TIGHT, l
+
+
 def test_non_default_taps(golden):
     """Content on a pooling blob, style on conv1_2/conv3_3 only, weighted layers."""
     om, _ = make_oracle('vgg16_avgpool')

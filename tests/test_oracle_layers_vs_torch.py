@@ -52,3 +52,41 @@ def test_pool_ceil_mode(h, w, mode):
             win = x[c, 2 * i:2 * i + 2, 2 * j:2 * j + 2]
             k = int(np.argmax(win.ravel()))
             assert aux[c, i, j] == (k // win.shape[1]) * 2 + (k % win.shape[1])
+
+
+def test_blob_with_two_consumers_adds_their_gradients():
+    """Caffe puts a Split layer behind a blob that feeds two layers (net.cpp: InsertSplits); the
+    reference's *_big prototxts have one (conv1_2 -> pool1, a dead end, and -> conv2_1:
+    vgg19_big.prototxt:62).  The pycaffe-shaped shim against torch autograd on that graph: the
+    gradient of a loss on conv2_1 and (second case) on conv2_1 AND pool1 reaches the image."""
+    from oracle import caffe_net
+    from style_transfer_amd.netspec import builtin_net
+    layers = [l for l in builtin_net('vgg19_big').as_dicts()][:8]      # input .. relu2_1
+    assert [l['name'] for l in layers][-4:] == ['relu1_2', 'pool1', 'conv2_1', 'relu2_1']
+    net = caffe_net.Net(layers, weights=None)
+    rng = np.random.RandomState(1)
+    x = rng.uniform(-100, 100, (3, 13, 18)).astype(np.float32)
+    net.blobs['data'].reshape(1, 3, 13, 18)
+    net.blobs['data'].data[0] = x
+    net.forward(end='relu2_1')
+    g2 = rng.standard_normal(net.blobs['conv2_1'].data.shape).astype(np.float32)
+    gp = rng.standard_normal(net.blobs['pool1'].data.shape).astype(np.float32)
+    for with_pool in (False, True):
+        for b in net.blobs.values():
+            b.diff[...] = 0
+        net._split.clear()
+        net.blobs['conv2_1'].diff[...] = g2
+        if with_pool:
+            net.blobs['pool1'].diff[...] = gp
+        net.backward(start='relu2_1')
+        xt = torch.tensor(x[None], requires_grad=True)
+        p = {k: (torch.tensor(w), torch.tensor(b)) for k, (w, b) in net.params.items()}
+        h = F.relu(F.conv2d(xt, *p['conv1_1'], padding=1))
+        h = F.relu(F.conv2d(h, *p['conv1_2'], padding=1))
+        out = (F.relu(F.conv2d(h, *p['conv2_1'], padding=1)) * torch.tensor(g2)).sum()
+        if with_pool:
+            out = out + (F.max_pool2d(h, 2, 2, ceil_mode=True) * torch.tensor(gp)).sum()
+        out.backward()
+        got, ref = net.blobs['data'].diff[0], xt.grad[0].numpy()
+        assert np.abs(ref).max() > 0
+        assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max(), with_pool
