@@ -52,7 +52,7 @@
 #ifndef STX_H2_SKIP
 #define STX_H2_SKIP 0   // timing experiments (tools/ubench/h2conv_bench.hip): 1 no staging, 2 no filter
 #endif                 // loads, 4 no patch loads in the main loop, 8 no stores, 16 no mask loads in the
-                       // epilogue.  Wrong results when non-zero.
+                       // epilogue, 32 / 64 the staging's vector work / LDS writes alone.  Wrong results when non-zero.
 
 namespace stx {
 
@@ -192,11 +192,14 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
             xr[n][i] = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[n], xs + (unsigned)i * HW4, 0));
     };
-    // One piece of the staging work of unit n: component c of channel pair pr (7 vector
-    // instructions), plus -- behind the second pair -- the two 8-byte writes of the component.
-    unsigned pkh[2], pkl[2];
-    auto piece = [&](int n, int c, int pr, char *vbuf, bool fix) __attribute__((always_inline)) {
-        if (c == 0 && pr == 0 && fix) {
+    // One piece of the staging work of unit n: component c of its four channels -- four additions, the
+    // split (eight v_fma_mix: hi = fp16(s v), lo = fp16(s v - hi), each ONE instruction with mixed
+    // fp32 / fp16 operands; the residual is exact) and the two 8-byte writes.  One asm block: around
+    // single-instruction asm statements the compiler pads with s_nop, every one an issue slot beside
+    // the MFMAs; inside, a partially written register (op_sel destination) is read two instructions
+    // after its last write at the earliest.
+    auto piece = [&](int n, int c, char *vbuf, bool fix) __attribute__((always_inline)) {
+        if (c == 0 && fix) {
             asm volatile("");      // (a scalar branch: workgroups on the left / right border only)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -211,29 +214,39 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 xr[n][i] = e;
             }
         }
-        const f32x4 da = xr[n][2 * pr], db = xr[n][2 * pr + 1];
-        const float va = c == 0 ? da.x - da.z : c == 1 ? da.y + da.z : c == 2 ? da.z - da.y : da.y - da.w;
-        const float vb = c == 0 ? db.x - db.z : c == 1 ? db.y + db.z : c == 2 ? db.z - db.y : db.y - db.w;
-        // hi = fp16(s v) for both channels of the pair; the residual s v - hi, exact; lo = fp16 of it
-        unsigned hi, lo;
-        float ra, rb;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(va), "v"(sv));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(vb), "v"(sv));
-        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
-            : "=v"(ra) : "v"(va), "v"(sv), "v"(hi));
-        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-            : "=v"(rb) : "v"(vb), "v"(sv), "v"(hi));
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(ra), "v"(rb));
-        pkh[pr] = hi, pkl[pr] = lo;
-        if (pr == 1) {
-            *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 0) * V_PIECE) = u32x2v{pkh[0], pkh[1]};
-            *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 1) * V_PIECE) = u32x2v{pkl[0], pkl[1]};
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 d = xr[n][i];
+            v[i] = c == 0 ? d.x - d.z : c == 1 ? d.y + d.z : c == 2 ? d.z - d.y : d.y - d.w;
         }
+        unsigned h0, h1, l0, l1;
+        if (STX_H2_SKIP & 64) {       // (timing experiment: the LDS writes without the vector work)
+            h0 = __builtin_bit_cast(unsigned, v[0]), h1 = __builtin_bit_cast(unsigned, v[1]);
+            l0 = __builtin_bit_cast(unsigned, v[2]), l1 = __builtin_bit_cast(unsigned, v[3]);
+        } else {
+            asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+                "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+                "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+                "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+                "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+                : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(sv));
+        }
+        if (STX_H2_SKIP & 32) {       // (timing experiment: the vector work without the LDS writes)
+            asm volatile("" :: "v"(h0), "v"(h1), "v"(l0), "v"(l1));
+            return;
+        }
+        *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 0) * V_PIECE) = u32x2v{h0, h1};
+        *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 1) * V_PIECE) = u32x2v{l0, l1};
     };
     auto stage_all = [&](int n, int buf) __attribute__((always_inline)) {
         char *vbuf = ldsb + buf * V_BYTES;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) piece(n, k >> 1, k & 1, vbuf, edge);
+        for (int c = 0; c < 4; ++c) piece(n, c, vbuf, edge);
     };
 
     // ---- A operand: fragments of (xi, channel block), [ky][block][piece], straight from the packed bank
@@ -393,10 +406,17 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // wave has issued its last reads of this chunk and written its share of the next by then).
     // The staging pieces are dealt out behind the MFMAs; sched_barrier pins the order.
     constexpr int PER_BLK = 3 * MB, SLOTS = 11 * PER_BLK;     // slots in front of the barrier
-    // unit 0's eight pieces (one component of one channel pair each) sit behind slots 1, 1 + STEP, ...;
-    // unit 1 (waves 0 and 1 only: a uniform branch) comes as four groups of one component each, between them
-    constexpr int STEP = (SLOTS - 2) / 12;
+    // unit 0's four pieces (one component each) sit behind slots 1, 1 + 2 STEP, ...; unit 1's (waves 0
+    // and 1 only: a uniform branch) between them.  (All of unit 0 first, unit 1 behind it, so that each
+    // unit's registers can be asked for again three quarters of a chunk ahead: 5350 -> 5720 cycles per
+    // chunk -- the vector work wants to be spread evenly.)
+    constexpr int STEP = (SLOTS - 2) / 8;
+#ifdef STX_H2_NO_BRANCH       // (timing experiment: no second unit, no border fix-up -- wrong results)
+    const bool two = false, edge_fix = false;
+#else
+    const bool edge_fix = edge;
     const bool two = n_units == 2;
+#endif
     auto run_chunk = [&](auto buf_c, int chunk, auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr int BUF = decltype(buf_c)::value, buf = BUF;
@@ -425,19 +445,17 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                     else if (MORE) a_load(as ^ 1, 0, chunk + 1);
                 }
                 if (MORE && !(STX_H2_SKIP & 1) && s >= 1 && (s - 1) % STEP == 0) {
-                    constexpr int k = (s - 1) / STEP;             // 0 .. 11
-                    if (k < 12 && k % 3 != 2) {                   // unit 0: pieces 0 .. 7
-                        constexpr int q = (k / 3) * 2 + k % 3;
-                        piece(0, q >> 1, q & 1, vnext, edge);
-                    } else if (k < 12 && two) {                   // unit 1: component k / 3
+                    constexpr int k = (s - 1) / STEP;             // 0 .. 7
+                    if (k < 8 && k % 2 == 0) {
+                        piece(0, k / 2, vnext, edge_fix);
+                    } else if (k < 8 && two) {
                         asm volatile("");                         // (keeps this a scalar branch)
-                        piece(1, k / 3, 0, vnext, edge);
-                        piece(1, k / 3, 1, vnext, edge);
+                        piece(1, k / 2, vnext, edge_fix);
                     }
                 }
                 if (MORE && !(STX_H2_SKIP & 4)) {
-                    if (s == 1 + 10 * STEP + 1 && chunk + 2 < c_end) x_load(0, chunk + 2);
-                    if (s == 1 + 11 * STEP + 1 && two && chunk + 2 < c_end) x_load(1, chunk + 2);
+                    if (s == 1 + 6 * STEP + 1 && chunk + 2 < c_end) x_load(0, chunk + 2);
+                    if (s == 1 + 7 * STEP + 1 && two && chunk + 2 < c_end) x_load(1, chunk + 2);
                 }
             });
             if (!LEAN && j == 3 && MORE && !(STX_H2_SKIP & 2)) a_load(ky, ky, chunk + 1);
