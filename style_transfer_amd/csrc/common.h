@@ -252,9 +252,9 @@ int wino2_max_slices(const ConvConfig &cfg, const ConvProblem &p);
 
 // 1-D Winograd F(2,3) on the fp16 matrix cores with two-piece operands (conv_h2.hip): fp32-class
 // accuracy at 0.28 of the fp32 2-D form's matrix time.  Config ids 300 (64 channels x 8 x 32 pixels per
-// workgroup) and 301 (128 channels); both read the same packed bank.
+// workgroup), 301 (128 channels) and 302 (64 channels x 16 x 32 pixels); all read the same packed bank.
 constexpr int kAmaxSlots = 64;
-ConvConfig h2_config(int mb);
+ConvConfig h2_config(int mb, int pb = 1);     // (1, 1), (2, 1) or (1, 2): ids 300 / 301 / 302
 ConvConfig h2_pick_config(const ConvProblem &p);    // the cheaper tiling by the round model (shape only)
 bool h2_usable(const ConvProblem &p);       // what the kernel takes (shape, epilogue, addressing)
 size_t h2_packed_floats(int K, int M);

@@ -67,16 +67,24 @@ typedef unsigned int u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned i
 
 constexpr int KC = 16;                      // input channels per chunk = one MFMA k-step
 constexpr int NT = 512;
-constexpr int PR = 8, PC = 32, TX = PC / 2; // pixel patch; x-tiles per patch row
-constexpr int XR = PR + 2;                  // input rows of the patch
-constexpr int RT = XR * TX;                 // (row, tile) positions of V: 160
-constexpr int V_PIECE = RT * 32;            // bytes of one [rt][16 ch] fp16 array
-constexpr int V_BYTES = 4 * 2 * V_PIECE;    // [xi][piece]: 40 KB
+constexpr int PC = 32, TX = PC / 2;         // pixel patch columns; x-tiles per patch row
+constexpr int EX_BYTES = 4 * 2 * 4 * 4 * 64 * 16;   // epilogue exchange: 128 KB
+// PB: pixel patches of 8 rows stacked in one workgroup (1 or 2): the staged patch, the accumulators
+// and the matrix work per filter fragment double, the prologue and the filter traffic do not
+template <int PB>
+struct Geo {
+    static constexpr int PR = 8 * PB;               // patch rows
+    static constexpr int XR = PR + 2;               // input rows of the patch
+    static constexpr int RT = XR * TX;              // (row, tile) positions of V: 160 / 288
+    static constexpr int V_PIECE = RT * 32;         // bytes of one [rt][16 ch] fp16 array
+    static constexpr int V_BYTES = 4 * 2 * V_PIECE; // [xi][piece]: 40 / 72 KB
+    static constexpr int FULL = RT * 4 / 512;       // staging units every thread has: 1 / 2
+    static constexpr int NU = FULL + 1;             // ... and one more for the threads of waves 0 and 1
+    static constexpr size_t kLds = (EX_BYTES > 2 * V_BYTES ? EX_BYTES : 2 * V_BYTES) + 64;   // + the waves' maxima
+};
 constexpr int FRAG = 1024;                  // one operand fragment: 64 lanes x 8 fp16
 constexpr int U_KY = 4 * 2 * FRAG;          // [xi][piece] of one (channel block, chunk, ky): 8 KB
 constexpr int U_BLK = 3 * U_KY;             // one (channel block, chunk): 24 KB
-constexpr int EX_BYTES = 4 * 2 * 4 * 4 * 64 * 16;   // epilogue exchange: 128 KB
-constexpr size_t kLdsBytes = (EX_BYTES > 2 * V_BYTES ? EX_BYTES : 2 * V_BYTES) + 64;    // + the waves' maxima
 constexpr int kHeaderFloats = 64;           // behind the bank: [0] max |U| (float bits), [1] the scale's exponent
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -115,8 +123,12 @@ __device__ long long g_h2_epi[8][8];     // epilogue, pass 0: loads issued, firs
 #define STX_H2_STAMP(i)
 #endif
 
-template <int EPI, int MB>
+template <int EPI, int MB, int PB>
 __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
+    using G = Geo<PB>;
+    constexpr int PR = G::PR, RT = G::RT, V_PIECE = G::V_PIECE, V_BYTES = G::V_BYTES, NU = G::NU, FULL = G::FULL;
+    constexpr size_t kLdsBytes = G::kLds;
+    constexpr int NJ = 4 * PB;                  // pixel blocks of 32 positions
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 #ifdef STX_H2_TIMING
     const long long t_start = clock64(), w_start = wall_clock64();
@@ -163,14 +175,14 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const float sv = pow2f(es);
     const float out_scale = pow2f(-es - ew);
 
-    // ---- staging role.  A unit = position rt of the V array x four channels (quad): 640 units per
-    // chunk; every thread has unit tid, the threads of waves 0 and 1 also unit 512 + tid.
-    const int n_units = wave < 2 ? 2 : 1;                 // wave-uniform
+    // ---- staging role.  A unit = position rt of the V array x four channels (quad): 640 (PB = 2: 1152)
+    // units per chunk; every thread has units tid (and 512 + tid), the threads of waves 0 and 1 one more.
+    const bool extra = wave < 2;                          // wave-uniform
     const bool edge = x0 == 0 || x0 + PC + 2 > a.W;       // workgroup-uniform
-    unsigned xvoff[2], v_dst[2];
-    bool left[2], ok2[2], ok3[2];
+    unsigned xvoff[NU], v_dst[NU];
+    bool left[NU], ok2[NU], ok3[NU];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NU; ++n) {
         const int u = tid + n * NT;
         const int quad = u & 3, rt = u >> 2;
         const int st_r = rt / TX, st_t = rt % TX;
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         v_dst[n] = (unsigned)(rt * 32 + ((quad * 8) ^ ((st_t & 8) << 1)));
     }
 
-    f32x4 xr[2][4];
+    f32x4 xr[NU][4];
     auto x_load = [&](int n, int chunk) __attribute__((always_inline)) {
         const unsigned xs = (unsigned)sgpr(chunk * KC) * HW4;
 #pragma unroll
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const unsigned w_blk0 = (unsigned)(mtile * 2 * MB + wh * MB);
     // MB = 1: the three kernel rows of a chunk, requested one chunk ahead; MB = 2 (half the registers
     // left): two slots, kernel row by kernel row, each requested while the one before it runs
-    constexpr bool LEAN = MB == 2;
+    constexpr bool LEAN = MB * PB == 2;
     f16x8 af[LEAN ? 2 : 3][MB][2];
     auto a_load = [&](int aslot, int ky, int chunk) __attribute__((always_inline)) {
 #pragma unroll
@@ -268,28 +280,29 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         }
     };
 
-    f32x16 acc[MB][4];
+    f32x16 acc[MB][NJ];
 #pragma unroll
     for (int b = 0; b < MB; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
 
-    // B fragments of block blk = 4 ky + j of a chunk, j = (m, s): rows 4m + s + ky and two below
+    // B fragments of block blk = NJ ky + j of a chunk, j = (m, s): rows 4m + s + ky and two below
     const unsigned b_base = (unsigned)(xi * 2 * V_PIECE + ((l31 >> 4) * 2 * TX + (l31 & 15)) * 32 +
                                        ((half * 16) ^ ((l31 & 8) << 1)));
     f16x8 bq[2][2];
     auto b_read = [&](int slot, int buf, int blk) __attribute__((always_inline)) {
-        const int j = blk & 3, ky = blk >> 2;
+        const int j = blk % NJ, ky = blk / NJ;
         const char *vb = ldsb + buf * V_BYTES + b_base + (4 * (j >> 1) + (j & 1) + ky) * TX * 32;
 #pragma unroll
         for (int q = 0; q < 2; ++q) bq[slot][q] = *reinterpret_cast<const f16x8 *>(vb + q * V_PIECE);
     };
 
     // ---- prologue
-    x_load(0, c_begin);
-    if (n_units == 2) x_load(1, c_begin);
+#pragma unroll
+    for (int n = 0; n < FULL; ++n) x_load(n, c_begin);
+    if (extra) x_load(FULL, c_begin);
     if (LEAN) {
         a_load(0, 0, c_begin);
     } else {
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 #pragma unroll
     for (int b = 0; b < MB; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[b][j]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[b][j]));
     // ---- the epilogue's addresses and descriptors, set up here, under the first loads' latency (a thousand
     // cycles of scalar and vector work where they stood, between the chunk loop and the first store).
     // Epilogue: components through LDS, [xi][wh][j][rq][lane] x (registers 4 rq .. 4 rq + 3), one
@@ -314,17 +327,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     }
     const int hh = wave & 1, mrow = (wave >> 1) & 1, rqp = wave >> 2;
     const bool weven = (a.W & 1) == 0;
-    const int yy = y0 + 4 * mrow + 2 * (l31 >> 4), xx0 = x0 + 2 * (l31 & 15);
+    const int xx0 = x0 + 2 * (l31 & 15);
     const unsigned plane_bytes = (unsigned)a.M * HW4;
-    unsigned vo[2][2];                        // [row][column] of the lane's 2 x 2 outputs
-    {
-        const unsigned lane_base = (unsigned)((4 * half) * HW + yy * a.W + xx0) * 4u;
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                vo[y][e] = (yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u : kOob;
-    }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         a.y + (EPI == kEpiPartial ? (size_t)kslice * a.M * HW : 0), 0, (int)plane_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
@@ -340,63 +344,77 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
         a.pool_codes, 0, a.pool_codes ? a.M * ph * pw : 0, 0x00020000);
-    const unsigned vpool = (yy < a.H && xx0 < a.W)
-                               ? (unsigned)((4 * half) * ph * pw + (yy >> 1) * pw + (xx0 >> 1)) * 4u
-                               : kOob;
     // ReLU sign nibbles of the output blob (ConvProblem::mask_codes): the lane's 2 x 2 outputs are one window
     const int cph = (a.H + 1) >> 1, cpw = (a.W + 1) >> 1;
     const __amdgpu_buffer_rsrc_t rmc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(a.mask_codes), 0, a.mask_codes ? a.M * cph * cpw : 0, 0x00020000);
-    const unsigned vmc = (yy < a.H && xx0 < a.W)
-                             ? (unsigned)((4 * half) * cph * cpw + (yy >> 1) * cpw + (xx0 >> 1))
-                             : kOob;
     const int M_ = a.M;
-    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, auto even_c) __attribute__((always_inline)) {
-        if (decltype(even_c)::value)
-            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[y][0], so, 0));
-        f32x2 v;
-        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][0], so, 0));
-        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[y][1], so, 0));
-        return v;
-    };
-    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, unsigned so, f32x2 v, auto even_c)
-                   __attribute__((always_inline)) {
-        if (STX_H2_SKIP & 8) {        // (timing experiment: the epilogue without its stores)
-            if (v.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, vo[y][0], so, 0);
-            return;
-        }
-        if (decltype(even_c)::value) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, vo[y][0], so, 0);
-        } else {
-            const float v0 = v.x, v1 = v.y;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, vo[y][0], so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, vo[y][1], so, 0);
-        }
+    // The lane's 2 x 2 outputs of a pass: rows yy, yy + 1 (yy = y0 + 8 pbi + 4 m + 2 (l31 >> 4)), columns
+    // xx0, xx0 + 1.  Byte offsets of the four outputs in a channel plane (out of range where the
+    // plane ends), of the window in the pooled plane / the nibble plane, the content map's rows.
+    struct LaneRows {
+        int yy;
+        unsigned vo[2][2], vpool, vmc;
     };
     const float *const content = a.inj.content;
     const int cw_ch = a.inj.win.ch, cw_cw = a.inj.win.cw, cw_oy = a.inj.win.oy - a.inj.win.sy,
               cw_ox = a.inj.win.ox - a.inj.win.sx;
-    int crow[2] = {0, 0}, ccol[2] = {0, 0};     // common.h: content_index, once per lane
+    auto lane_rows = [&](int pbi) __attribute__((always_inline)) {
+        LaneRows r;
+        r.yy = y0 + 8 * pbi + 4 * mrow + 2 * (l31 >> 4);
+        const unsigned lane_base = (unsigned)((4 * half) * HW + r.yy * a.W + xx0) * 4u;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                r.vo[y][e] = (r.yy + y < a.H && xx0 + e < a.W) ? lane_base + (unsigned)(y * a.W + e) * 4u : kOob;
+        const bool in = r.yy < a.H && xx0 < a.W;
+        r.vpool = in ? (unsigned)((4 * half) * ph * pw + (r.yy >> 1) * pw + (xx0 >> 1)) * 4u : kOob;
+        r.vmc = in ? (unsigned)((4 * half) * cph * cpw + (r.yy >> 1) * cpw + (xx0 >> 1)) : kOob;
+        return r;
+    };
+    const LaneRows rows0 = lane_rows(0);
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, const LaneRows &lr, int y, unsigned so, auto even_c)
+                   __attribute__((always_inline)) {
+        if (decltype(even_c)::value)
+            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, lr.vo[y][0], so, 0));
+        f32x2 v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lr.vo[y][0], so, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lr.vo[y][1], so, 0));
+        return v;
+    };
+    auto st2 = [&](const __amdgpu_buffer_rsrc_t &rs, const LaneRows &lr, int y, unsigned so, f32x2 v, auto even_c)
+                   __attribute__((always_inline)) {
+        if (STX_H2_SKIP & 8) {        // (timing experiment: the epilogue without its stores)
+            if (v.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, lr.vo[y][0], so, 0);
+            return;
+        }
+        if (decltype(even_c)::value) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, v), rs, lr.vo[y][0], so, 0);
+        } else {
+            const float v0 = v.x, v1 = v.y;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs, lr.vo[y][0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rs, lr.vo[y][1], so, 0);
+        }
+    };
+    int ccol[2] = {0, 0};
     if (EPI == kEpiDgradInject && content) {
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const bool ok = yy + y < a.H && xx0 < a.W;
-            int r = (cw_oy + (ok ? yy + y : 0)) % cw_ch;
-            crow[y] = (r < 0 ? r + cw_ch : r) * cw_cw;
-        }
-#pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const bool ok = yy < a.H && xx0 < a.W;
+            const bool ok = rows0.yy < a.H && xx0 < a.W;
             const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
             int r = (cw_ox + x) % cw_cw;
             ccol[e] = r < 0 ? r + cw_cw : r;
         }
     }
-    stage_all(0, 0);
-    if (c_begin + 1 < c_end) x_load(0, c_begin + 1);
-    if (n_units == 2) {
-        stage_all(1, 0);
-        if (c_begin + 1 < c_end) x_load(1, c_begin + 1);
+#pragma unroll
+    for (int n = 0; n < FULL; ++n) {
+        stage_all(n, 0);
+        if (c_begin + 1 < c_end) x_load(n, c_begin + 1);
+    }
+    if (extra) {
+        stage_all(FULL, 0);
+        if (c_begin + 1 < c_end) x_load(FULL, c_begin + 1);
     }
     lds_barrier();
     b_read(0, 0, 0);
@@ -405,31 +423,34 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // while the block before it runs; the hand-over barrier sits before the last block (every
     // wave has issued its last reads of this chunk and written its share of the next by then).
     // The staging pieces are dealt out behind the MFMAs; sched_barrier pins the order.
-    constexpr int PER_BLK = 3 * MB, SLOTS = 11 * PER_BLK;     // slots in front of the barrier
+    constexpr int NBLK = 3 * NJ;                                     // blocks of a chunk: 12 / 24
+    constexpr int PER_BLK = 3 * MB, SLOTS = (NBLK - 1) * PER_BLK;    // slots in front of the barrier
     // unit 0's four pieces (one component each) sit behind slots 1, 1 + 2 STEP, ...; unit 1's (waves 0
     // and 1 only: a uniform branch) between them.  (All of unit 0 first, unit 1 behind it, so that each
     // unit's registers can be asked for again three quarters of a chunk ahead: 5350 -> 5720 cycles per
     // chunk -- the vector work wants to be spread evenly.)
-    constexpr int STEP = (SLOTS - 2) / 8;
+    constexpr int NP = 4 * NU;                                       // staging pieces: unit k % NU, component k / NU
+    constexpr int STEP = (SLOTS - 2) / NP;
 #ifdef STX_H2_NO_BRANCH       // (timing experiment: no second unit, no border fix-up -- wrong results)
     const bool two = false, edge_fix = false;
+    (void)extra;
 #else
     const bool edge_fix = edge;
-    const bool two = n_units == 2;
+    const bool two = extra;
 #endif
     auto run_chunk = [&](auto buf_c, int chunk, auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr int BUF = decltype(buf_c)::value, buf = BUF;
         char *vnext = ldsb + (buf ^ 1) * V_BYTES;
-        static_for<0, 12>([&](auto blk_c) __attribute__((always_inline)) {
+        static_for<0, NBLK>([&](auto blk_c) __attribute__((always_inline)) {
             constexpr int blk = decltype(blk_c)::value;
-            constexpr int ky = blk >> 2, j = blk & 3, slot = blk & 1;
-            if (blk == 11) {
+            constexpr int ky = blk / NJ, j = blk % NJ, slot = blk & 1;
+            if (blk == NBLK - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (blk < 11) b_read(slot ^ 1, buf, blk + 1);
+            if (blk < NBLK - 1) b_read(slot ^ 1, buf, blk + 1);
             else if (MORE) b_read(0, buf ^ 1, 0);
             static_for<0, PER_BLK>([&](auto m_c) __attribute__((always_inline)) {
                 constexpr int m = decltype(m_c)::value;
@@ -445,20 +466,24 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                     else if (MORE) a_load(as ^ 1, 0, chunk + 1);
                 }
                 if (MORE && !(STX_H2_SKIP & 1) && s >= 1 && (s - 1) % STEP == 0) {
-                    constexpr int k = (s - 1) / STEP;             // 0 .. 7
-                    if (k < 8 && k % 2 == 0) {
-                        piece(0, k / 2, vnext, edge_fix);
-                    } else if (k < 8 && two) {
+                    constexpr int k = (s - 1) / STEP;             // 0 .. NP - 1
+                    if (k < NP && k % NU < FULL) {
+                        piece(k % NU, k / NU, vnext, edge_fix);
+                    } else if (k < NP && two) {
                         asm volatile("");                         // (keeps this a scalar branch)
-                        piece(1, k / 2, vnext, edge_fix);
+                        piece(FULL, k / NU, vnext, edge_fix);
                     }
                 }
                 if (MORE && !(STX_H2_SKIP & 4)) {
-                    if (s == 1 + 6 * STEP + 1 && chunk + 2 < c_end) x_load(0, chunk + 2);
-                    if (s == 1 + 7 * STEP + 1 && two && chunk + 2 < c_end) x_load(1, chunk + 2);
+                    // (a unit's registers are asked for again right behind its last piece)
+                    static_for<0, NU>([&](auto u_c) __attribute__((always_inline)) {
+                        constexpr int u = decltype(u_c)::value;
+                        if (s == 1 + (3 * NU + u) * STEP + 1 && (u < FULL || two) && chunk + 2 < c_end)
+                            x_load(u, chunk + 2);
+                    });
                 }
             });
-            if (!LEAN && j == 3 && MORE && !(STX_H2_SKIP & 2)) a_load(ky, ky, chunk + 1);
+            if (!LEAN && j == NJ - 1 && MORE && !(STX_H2_SKIP & 2)) a_load(ky, ky, chunk + 1);
         });
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -510,7 +535,18 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 #endif
     auto epilogue_pass = [&](auto pass_c, auto even_c) __attribute__((always_inline)) {
         constexpr int pass = decltype(pass_c)::value;
-        const int cblk = m0 + (hh * MB + pass) * 32;
+        constexpr int mbi = pass % MB, pbi = pass / MB;        // channel block of the wave, patch of the stack
+        const LaneRows lr = pbi == 0 ? rows0 : lane_rows(pbi);
+        int crow[2] = {0, 0};                                  // common.h: content_index, once per lane and pass
+        if (EPI == kEpiDgradInject && content) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const bool ok = lr.yy + y < a.H && xx0 < a.W;
+                int q = (cw_oy + (ok ? lr.yy + y : 0)) % cw_ch;
+                crow[y] = (q < 0 ? q + cw_ch : q) * cw_cw;
+            }
+        }
+        const int cblk = m0 + (hh * MB + mbi) * 32;
         auto chan = [&](int n) __attribute__((always_inline)) {     // n = 4 rqi + e
             const int c0 = cblk + (n & 3) + 8 * (2 * rqp + (n >> 2));
             return sgpr(c0 < M_ ? c0 : M_);
@@ -527,11 +563,11 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                                                                rbias, (unsigned)half * 16u, (unsigned)c * 4u, 0))
                                : 0.f;
             } else if (EPI != kEpiPartial) {
-                if (a.mask_codes) mkb[n] = __builtin_amdgcn_raw_buffer_load_b8(rmc, vmc, (unsigned)(c * cph * cpw), 0);
+                if (a.mask_codes) mkb[n] = __builtin_amdgcn_raw_buffer_load_b8(rmc, lr.vmc, (unsigned)(c * cph * cpw), 0);
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
-                    if (!a.mask_codes && a.mask && !(STX_H2_SKIP & 16)) mk[2 * n + y] = ld2(rmask, y, so, even_c);
-                    if (EPI == kEpiDgradInject && a.inj.sgrad) sg[2 * n + y] = ld2(rsg, y, so, even_c);
+                    if (!a.mask_codes && a.mask && !(STX_H2_SKIP & 16)) mk[2 * n + y] = ld2(rmask, lr, y, so, even_c);
+                    if (EPI == kEpiDgradInject && a.inj.sgrad) sg[2 * n + y] = ld2(rsg, lr, y, so, even_c);
                 }
             }
         }
@@ -543,8 +579,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
                 ex[(((xi * 2 + wh) * 4 + j) * 4 + rq) * 64 + lane] =
-                    f32x4{acc[pass][j][4 * rq], acc[pass][j][4 * rq + 1], acc[pass][j][4 * rq + 2],
-                          acc[pass][j][4 * rq + 3]};
+                    f32x4{acc[mbi][4 * pbi + j][4 * rq], acc[mbi][4 * pbi + j][4 * rq + 1],
+                          acc[mbi][4 * pbi + j][4 * rq + 2], acc[mbi][4 * pbi + j][4 * rq + 3]};
         __syncthreads();
         STX_H2_STAMP(2);
 #pragma unroll
@@ -590,7 +626,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                         if (EPI == kEpiDgradInject) {
                             if (content) {
                                 // (one layer per tile evaluation takes this: read where it is used)
-                                const f32x2 ft = ld2(rft, y, so, even_c);
+                                const f32x2 ft = ld2(rft, lr, y, so, even_c);
                                 const int mm = c + 4 * half;
                                 const int cm = mm < a.M ? mm : 0;     // (lanes past M store nothing)
                                 const float *cp = content + (size_t)cm * cw_ch * cw_cw + crow[y];
@@ -606,15 +642,15 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 }
 #pragma unroll
                 for (int y = 0; y < 2; ++y) {
-                    if (EPI != kEpiForward || !a.skip_y) st2(ry, y, so, v[y], even_c);
+                    if (EPI != kEpiForward || !a.skip_y) st2(ry, lr, y, so, v[y], even_c);
                     if (EPI != kEpiPartial)
-                        amax = fmaxf(amax, fmaxf(vo[y][0] != kOob ? fabsf(v[y].x) : 0.f,
-                                                 vo[y][1] != kOob ? fabsf(v[y].y) : 0.f));
+                        amax = fmaxf(amax, fmaxf(lr.vo[y][0] != kOob ? fabsf(v[y].x) : 0.f,
+                                                 lr.vo[y][1] != kOob ? fabsf(v[y].y) : 0.f));
                 }
                 // the lane's 2x2 outputs are one window of the 2x2/2 pooling layer that follows
                 // (pool.hip's arithmetic; ceil mode: the second row may be missing)
                 if (EPI == kEpiForward && a.pool_out) {
-                    const bool hy = yy + 1 < a.H;
+                    const bool hy = lr.yy + 1 < a.H;
                     float pr;
                     if (a.pool_mode == STX_POOL_MAX) {
                         pr = fmaxf(v[0].x, v[0].y);
@@ -622,20 +658,20 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                     } else {
                         pr = (v[0].x + v[0].y + (hy ? v[1].x : 0.f) + (hy ? v[1].y : 0.f)) * (hy ? 0.25f : 0.5f);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, vpool,
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, lr.vpool,
                                                           (unsigned)c * (unsigned)(ph * pw * 4), 0);
                     if (a.pool_codes) {
                         const unsigned code = a.pool_mode == STX_POOL_MAX
                                                   ? pool_max_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy)
                                                   : pool_ave_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy);
-                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rcodes, vpool >> 2,
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rcodes, lr.vpool >> 2,
                                                              (unsigned)c * (unsigned)(ph * pw), 0);
                     }
                 }
             }
         }
     };
-    static_for<0, MB>([&](auto pass_c) __attribute__((always_inline)) {
+    static_for<0, MB * PB>([&](auto pass_c) __attribute__((always_inline)) {
         [[maybe_unused]] constexpr int pass = decltype(pass_c)::value;
         if (weven) epilogue_pass(pass_c, yes{});
         else epilogue_pass(pass_c, no{});
@@ -784,15 +820,16 @@ int h2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int tra
     return STX_OK;
 }
 
-ConvConfig h2_config(int mb) {
+// ids 300: 64 channels x 8 x 32 pixels per workgroup, 301: 128 channels x 8 x 32, 302: 64 channels x 16 x 32
+ConvConfig h2_config(int mb, int pb) {
     ConvConfig c;
-    c.id = 300 + (mb == 2 ? 1 : 0);
-    c.bm = 64 * (mb == 2 ? 2 : 1);
+    c.id = mb == 2 ? 301 : pb == 2 ? 302 : 300;
+    c.bm = mb == 2 ? 128 : 64;
     c.kc = KC;
-    c.pr = PR;
+    c.pr = c.id == 302 ? 16 : 8;
     c.pc = PC;
     c.threads = NT;
-    c.lds_bytes = kLdsBytes;
+    c.lds_bytes = c.id == 302 ? Geo<2>::kLds : Geo<1>::kLds;
     return c;
 }
 
@@ -808,14 +845,17 @@ bool h2_usable(const ConvProblem &p) {
 }
 
 // K split of a launch and the channel tiling: the round model of conv_wino2.hip with this kernel's
-// measured chunk (16 channels: 2.0 us for 64 channels x 256 pixels, 2.75 us for 128 channels) and its
+// measured chunk (16 channels: 2.0 us for 64 channels x 256 pixels, 2.75 us for 128 channels, 3.5 us for
+// two stacked patches) and its
 // prologue + epilogue (8.5 / 17 us) -- whole rounds of 256 workgroups plus the reduce pass over the
 // slices.  Shape and epilogue only, never timing.
-static double h2_plan(int mb, const ConvProblem &p, int *factor) {
+static double h2_plan(const ConvConfig &cfg, const ConvProblem &p, int *factor) {
     const int n_pairs = p.K / (2 * KC);
-    const long n = (long)ceil_div(p.M, 64 * mb) * ceil_div(p.H, PR) * ceil_div(p.W, PC);
+    const long n = (long)ceil_div(p.M, cfg.bm) * ceil_div(p.H, cfg.pr) * ceil_div(p.W, PC);
     const double out_mb = 4e-6 * p.M * (double)p.H * p.W;
-    const double t_chunk = mb == 2 ? 2.75 : 2.0, t_fixed = mb == 2 ? 17.0 : 8.5;
+    // (128 channels or two stacked patches: twice the matrix work per chunk; the stacked patches also
+    // stage twice as much, 7 000 cycles per chunk against 5 400)
+    const double t_chunk = cfg.id == 301 ? 2.75 : cfg.id == 302 ? 3.5 : 2.0, t_fixed = cfg.id != 300 ? 17.0 : 8.5;
     const bool may_split = p.epilogue == kEpiForward || p.epilogue == kEpiDgrad;
     double best_cost = 0;
     int best = 1;
@@ -834,14 +874,24 @@ static double h2_plan(int mb, const ConvProblem &p, int *factor) {
 
 int h2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p) {
     int f;
-    h2_plan(cfg.bm / 64, p, &f);
+    h2_plan(cfg, p, &f);
     return f;
 }
 
+// The cheapest of the three tilings by the round model: 128 channels where the channel count allows
+// (the staged patch serves twice the matrix work), else two stacked patches (the filter fragments
+// and the prologue do), else the plain one (small planes: more, shorter workgroups).
 ConvConfig h2_pick_config(const ConvProblem &p) {
-    int f1, f2;
-    if (p.M % 128 != 0) return h2_config(1);
-    return h2_plan(2, p, &f2) < h2_plan(1, p, &f1) ? h2_config(2) : h2_config(1);
+    int f;
+    ConvConfig best = h2_config(1, 1);
+    double best_cost = h2_plan(best, p, &f);
+    const ConvConfig cand[2] = {h2_config(2, 1), h2_config(1, 2)};
+    for (int i = 0; i < 2; ++i) {
+        if (i == 0 && p.M % 128 != 0) continue;
+        const double c = h2_plan(cand[i], p, &f);
+        if (c < best_cost) best_cost = c, best = cand[i];
+    }
+    return best;
 }
 
 bool h2_fuses_pool(const ConvProblem &p) {
@@ -849,9 +899,10 @@ bool h2_fuses_pool(const ConvProblem &p) {
            (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
-template <int EPI, int MB>
+template <int EPI, int MB, int PB>
 static int h2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_h2_kernel<EPI, MB>;
+    auto kern = conv_h2_kernel<EPI, MB, PB>;
+    constexpr size_t kLdsBytes = Geo<PB>::kLds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
@@ -869,7 +920,6 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
                   p.x_amax ? "given" : "missing");
         return STX_ERR_UNSUPPORTED;
     }
-    const int mb = cfg.bm / 64;
     WinoArgs a;
     a.x = p.x;
     a.w = p.w;
@@ -882,7 +932,7 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
     a.W = p.W;
     a.n_chunks = p.K / KC;
     a.tiles_x = ceil_div(p.W, PC);
-    a.tiles_y = ceil_div(p.H, PR);
+    a.tiles_y = ceil_div(p.H, cfg.pr);
     a.m_tiles = ceil_div(p.M, cfg.bm);
     a.ksplit = 1;
     a.w_tile_stride = 0;
@@ -912,9 +962,11 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
         a.skip_y = p.skip_y && p.pool_codes != nullptr;
     }
     const int epi = split ? kEpiPartial : inject ? kEpiDgradInject : p.epilogue;
-#define STX_H2_CASE(E)                                                                  \
-    case E:                                                                             \
-        STX_TRY(mb == 2 ? (h2_launch_epi<E, 2>(s, a, n_wg)) : (h2_launch_epi<E, 1>(s, a, n_wg))); \
+#define STX_H2_CASE(E)                                                                   \
+    case E:                                                                              \
+        STX_TRY(cfg.id == 301   ? (h2_launch_epi<E, 2, 1>(s, a, n_wg))                   \
+                : cfg.id == 302 ? (h2_launch_epi<E, 1, 2>(s, a, n_wg))                   \
+                                : (h2_launch_epi<E, 1, 1>(s, a, n_wg)));                 \
         break;
     switch (epi) {
         STX_H2_CASE(kEpiForward)

@@ -321,7 +321,7 @@ static const WinoVariant kWino[] = {
 };
 
 ConvConfig wino_config_by_id(int id) {
-    if (id >= 200) return h2_config(id - 200 + 1);
+    if (id >= 200) return id == 202 ? h2_config(1, 2) : h2_config(id - 200 + 1);
     if (id >= 110) return wino4_config(id - 110);
     if (id >= 100) return wino2_config(id - 100);
     const WinoVariant &v = kWino[id];

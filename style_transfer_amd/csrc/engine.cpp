@@ -527,7 +527,8 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 // tests/ holds except the reference's L-BFGS trajectory of BASELINE config 4 in miniature, which leaves
 // its 2e-4 band at the second step (5.7e-4: the line search amplifies one flip).
 // The backward pass decides nothing: its rounding moves the gradient by 1e-7 and no further.
-// STX_CONV_ALGO=h2|h2a|h2b forces the kernel (either / the 64- / the 128-channel tiling) wherever it applies.
+// STX_CONV_ALGO=h2|h2a|h2b|h2c forces the kernel (any / the 64- / the 128-channel / the two-patch tiling)
+// wherever it applies.
 static bool h2_enabled() {
     const char *algo = getenv("STX_CONV_ALGO");
     if (algo && *algo) return !strncmp(algo, "h2", 2);
@@ -539,9 +540,10 @@ static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
     const char *algo = getenv("STX_CONV_ALGO");
     int force = 0;
     if (algo && *algo) {
-        if (!strcmp(algo, "h2")) force = 3;
+        if (!strcmp(algo, "h2")) force = 4;
         else if (!strcmp(algo, "h2a")) force = 1;
         else if (!strcmp(algo, "h2b")) force = 2;
+        else if (!strcmp(algo, "h2c")) force = 3;
         else return false;             // some other kernel family was asked for
     }
     const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
@@ -549,7 +551,7 @@ static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
                                                 : (envb ? atoi(envb) : env && atoi(env) <= 0 ? 0 : 64);
     if (!force && (min_k <= 0 || p.K < min_k || p.M < 64)) return false;
     if (!h2_usable(p)) return false;
-    *out = force == 1 ? h2_config(1) : force == 2 ? h2_config(2) : h2_pick_config(p);
+    *out = force == 1 ? h2_config(1) : force == 2 ? h2_config(2) : force == 3 ? h2_config(1, 2) : h2_pick_config(p);
     return true;
 }
 

@@ -22,7 +22,7 @@ CONV_CASES = [  # (Cin, Cout, H, W): SURVEY section 8c list + shapes that hit ev
     # degenerate planes and ragged channel counts (partial chunks, partial channel tiles)
     (8, 33, 1, 1), (9, 65, 2, 3), (24, 96, 5, 67), (130, 66, 31, 33)]
 # every convolution kernel family on every shape it accepts; None = the engine's own choice
-CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino2c', 'wino4a', 'wino4b', 'wino4c', 'h2a', 'h2b']
+CONV_ALGOS = [None, 'direct', 'wino1', 'wino2a', 'wino2b', 'wino2c', 'wino4a', 'wino4b', 'wino4c', 'h2a', 'h2b', 'h2c']
 
 
 @pytest.mark.parametrize('algo', CONV_ALGOS)
@@ -77,7 +77,7 @@ H2_RANGES = {
 }
 
 
-@pytest.mark.parametrize('algo', ['h2a', 'h2b'])
+@pytest.mark.parametrize('algo', ['h2a', 'h2b', 'h2c'])
 @pytest.mark.parametrize('kind', sorted(H2_RANGES))
 @pytest.mark.parametrize('cin,cout,h,w', H2_SHAPES)
 def test_conv_fp16_split_over_input_ranges(cin, cout, h, w, kind, algo, monkeypatch):
