@@ -524,8 +524,8 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 //   backward: at least STX_CONV_H2_BWD channels of incoming gradient (default 64).
 // Why two thresholds: a forward blob that differs in its last bits flips ReLU / max-pooling near-ties, and
 // the two 64-channel layers hold most of a tile's decisions -- with them on this kernel every bound of
-// tests/ holds except the reference's L-BFGS trajectory of BASELINE config 4 in miniature, which leaves
-// its 2e-4 band at the second step (5.7e-4: the line search amplifies one flip).
+// tests/ holds except the reference's L-BFGS trajectory of BASELINE config 4 in miniature (two tests of
+// that one run), which leaves its 2e-4 band at the second step (5.7e-4: the line search amplifies one flip).
 // The backward pass decides nothing: its rounding moves the gradient by 1e-7 and no further.
 // STX_CONV_ALGO=h2|h2a|h2b|h2c forces the kernel (any / the 64- / the 128-channel / the two-patch tiling)
 // wherever it applies.
