@@ -16,8 +16,8 @@ content and style pictures (no network).
 `value` is ALWAYS that workload -- the fixed 2048 x 2048 image, four tiles per step -- so for
 N > 1 it is STRONG scaling, exactly what the metric names ("VGG-19 2048px/1024-tile, 1/2/4/8
 MI355X"): 2 / 1 / 1 tiles per GPU at N = 2 / 4 / 8 (at N = 8 four GPUs have no tile and the line
-says so).  At N = 1 the step loop runs through TileFarm, the product's own driver (four HIP
-streams on the GPU).  At N > 1 it runs one process per GPU as the benchmark contract prescribes:
+says so).  At N = 1 the step loop runs through TileFarm, the product's own driver (two HIP
+streams on the GPU, TileFarm's default; STX_STREAMS_PER_GPU overrides it for A/B runs).  At N > 1 it runs one process per GPU as the benchmark contract prescribes:
 rank 0 owns the image and the optimizer, tiles go out and gradients come back as batched
 point-to-point transfers over RCCL, no collective on the data path.
 
@@ -73,7 +73,7 @@ NOMINAL_CLOCK_MHZ = 2400.0
 # them in fp32 -- every parity bound of tests/ is the float32 kernels' own (STX_CONV_H2=0: fp32 MFMAs only)
 DTYPE = ('f32' if os.environ.get('STX_CONV_H2') == '0' and not os.environ.get('STX_CONV_H2_BWD')
          else 'f32 (fp16x2-split MFMA, fp32 accumulate)')
-STREAMS_PER_GPU = 4                    # engines (HIP streams) a GPU runs its tiles of a step on
+STREAMS_PER_GPU = int(os.environ.get('STX_STREAMS_PER_GPU', '2'))    # engines (HIP streams) a GPU runs its tiles of a step on
 STRONG_GRID = (2, 2)                   # BASELINE's metric: --size 2048 --tile-size 1024
 CONFIG4_GRID = (4, 4)                  # BASELINE config 4's top scale: --size 4096, 16 tiles
 WEAK_GRIDS = {1: (2, 2), 2: (2, 4), 4: (4, 4), 8: (4, 8)}    # four tiles per GPU
@@ -582,7 +582,7 @@ def base_line(opts, world, rows, cols, elapsed, loss, eng, timed_group_ms, scali
 
 
 def bench_single(opts, net, weights, device_index, rows, cols):
-    """N = 1: the step loop through TileFarm (four engines = four HIP streams on the GPU)."""
+    """N = 1: the step loop through TileFarm (STREAMS_PER_GPU engines = HIP streams on the GPU)."""
     from style_transfer_amd import lib
     job = FarmJob(net, weights, [device_index], rows, cols)
     elapsed, loss = job.timed(opts.steps, opts.warmup)

@@ -708,13 +708,20 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 // whose producer did not fuse, the gradient the loss terms start from).
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *slots) {
     float m = 0.f;
-    const size_t n4 = n >> 2;
-    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    // 16-byte loads over the aligned middle; the (at most three) floats in front of it and behind it one by one
+    const size_t head = ((16 - (reinterpret_cast<size_t>(x) & 15)) & 15) >> 2;
+    const size_t h = head < n ? head : n;
+    const size_t n4 = (n - h) >> 2;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + h);
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const f32x4 v = x4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) m = fmaxf(m, fabsf(x[threadIdx.x]));
+        const size_t tail = h + (n4 << 2);
+        if (tail + threadIdx.x < n && threadIdx.x < 4) m = fmaxf(m, fabsf(x[tail + threadIdx.x]));
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     __shared__ float wmax[4];
@@ -727,8 +734,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
 
 int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots) {
     STX_HIP(hipMemsetAsync(slots, 0, kAmaxSlots * sizeof(unsigned), s));
-    if ((reinterpret_cast<size_t>(x) & 15) != 0) {
-        set_error("absmax_launch: unaligned array");
+    if ((reinterpret_cast<size_t>(x) & 3) != 0) {
+        set_error("absmax_launch: the array is not float-aligned");
         return STX_ERR_ARG;
     }
     const int blocks = (int)std::min<size_t>((n / 4 + 2047) / 2048 + 1, 1024);

@@ -84,12 +84,19 @@ class TileFarm:
     """One host process, one engine per entry of ``devices`` (the reference's ``--devices``)."""
 
     def __init__(self, net, devices=(0,), weights=None, verbose=True, engines=None,
-                 streams_per_device=4, force_staging=None):
+                 streams_per_device=None, force_staging=None):
         """``streams_per_device``: up to this many engines (each with its own HIP stream and
         activation buffers) are created per GPU, lazily, when a step has more tiles than GPUs.
         Tiles of one step then overlap on a GPU, which fills the tails and launch gaps of tiles
-        that do not saturate the chip on their own (measured on MI355X: 4 x 724^2 tiles per step
-        33.3 -> 27.2 ms, 16 x 256^2 tiles 25.9 -> 17.2 ms; 1024^2 tiles gain ~2 %)."""
+        that do not saturate the chip on their own.  Default 2 (STX_STREAMS_PER_GPU overrides): with the
+        fp32 kernels of rounds 1-4 four streams were best (4 x 724^2 tiles per step 33.3 -> 27.2 ms,
+        1024^2 tiles + 2 %); the fp16-split convolutions fill a launch better and their workgroups
+        own a CU each, so two tiles side by side are enough and four only take each other's cache
+        -- round 5, alternating on one box: bench.py 248.4 / 248.6 tile-iterations/s with two streams,
+        241.8 / 242.3 with four, 237.5 with three, 228.1 with one; BASELINE config 4 13.5 s of
+        stepping against 14.1; the four 724^2 tiles of a 1448 scale 9.92 against 9.84 ms."""
+        if streams_per_device is None:
+            streams_per_device = int(os.environ.get('STX_STREAMS_PER_GPU', '2'))
         self.net = net
         self.verbose = verbose
         # force_staging (or STX_FARM_FORCE_STAGING=1): treat every engine but the master as if it
