@@ -333,10 +333,12 @@ __device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, i
 int content_sums_launch(hipStream_t s, const float *feat, const float *content,
                         const ContentWindow &win, float *sums /*[2]*/);
 // diff (=|+=) coef / (abs_sum/n + EPS) * term, term = S (style) or F - Fc (content).
+// y_amax (optional, zeroed by the caller): max |value written| for a conv_h2 launch that reads diff next
 int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
-                        const float *abs_sum, float coef, bool accumulate);
+                        const float *abs_sum, float coef, bool accumulate, unsigned *y_amax = nullptr);
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
-                          const ContentWindow &win, const float *sums, float coef, bool accumulate);
+                          const ContentWindow &win, const float *sums, float coef, bool accumulate,
+                          unsigned *y_amax = nullptr);
 int relu_inplace_launch(hipStream_t s, float *x, size_t n);
 int sum_partials_launch(hipStream_t s, const float *partials, int n, float *out);
 int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, const float *b, int nb,

@@ -1681,13 +1681,22 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     auto inject = [&](size_t k, bool &diff_written) -> int {
         Blob &b = e->blobs[order[k].blob];
         ProfScope scope(e, "inject " + b.name, 0.0);
-        for (const Term &t : terms[k]) {       // content terms come first, like the reference
+        b.amax_diff = -1;
+        for (size_t ti = 0; ti < terms[k].size(); ++ti) {       // content terms come first, like the reference
+            const Term &t = terms[k][ti];
+            // the last term's kernel writes the blob's final gradient: it leaves its maximum for the
+            // fp16-split convolution that reads it next (the slots were zeroed when the walk began)
+            unsigned *amax = nullptr;
+            if (ti + 1 == terms[k].size() && h2_enabled()) {
+                amax = e->amax_slots(order[k].blob, true);
+                b.amax_diff = order[k].blob;
+            }
             if (t.style)
                 STX_TRY(inject_style_launch(e->stream, b.diff.f(), t.src, b.count(), t.sums, t.coef,
-                                            diff_written));
+                                            diff_written, amax));
             else
                 STX_TRY(inject_content_launch(e->stream, b.diff.f(), b.data.f(), t.src, t.win,
-                                              t.sums, t.coef, diff_written));
+                                              t.sums, t.coef, diff_written, amax));
             diff_written = true;
         }
         return STX_OK;
@@ -1752,8 +1761,10 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         cur = L.bottom_blob;
         if (k >= 0 && !fused) {
             bool written = true;   // the upstream gradient is already in diff
+            // (the terms are added behind the kernel that left a maximum; the slots hold that one, and
+            // max is monotone: zero them so that the last term's kernel leaves the new one)
+            STX_HIP(hipMemsetAsync(e->amax_slots(L.bottom_blob, true), 0, kAmaxSlots * sizeof(unsigned), e->stream));
             STX_TRY(inject((size_t)k, written));
-            bot.amax_diff = -1;    // (the terms were added behind the kernel that left the maximum)
         }
     }
     STX_TRY(end_timing(e));

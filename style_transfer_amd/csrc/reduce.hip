@@ -112,26 +112,45 @@ int content_sums_launch(hipStream_t s, const float *feat, const float *content,
     return STX_OK;
 }
 
+// max |value written| of a launch into kAmaxSlots words of float bits (ConvProblem::y_amax; conv_h2.hip
+// reads it as the scale of its input): one atomic per block
+__device__ __forceinline__ void block_amax(float amax, unsigned *y_amax) {
+    if (!y_amax) return;            // (uniform)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(y_amax + (blockIdx.x & (kAmaxSlots - 1)),
+                  __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 template <bool ACC>
 __global__ __launch_bounds__(256) void inject_style_kernel(float *__restrict__ diff,
                                                            const float *__restrict__ sgrad, size_t n,
                                                            const float *__restrict__ abs_sum,
-                                                           float coef) {
+                                                           float coef, unsigned *y_amax) {
     // normalize(): x *= 1 / (sum|x| / size + EPS)   (num_utils.py:85-87)
     const float scale = coef * (1.0f / (abs_sum[0] / (float)n + kEps));
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = scale * sgrad[i];
-        diff[i] = ACC ? diff[i] + v : v;
+        const float o = ACC ? diff[i] + v : v;
+        diff[i] = o;
+        amax = fmaxf(amax, fabsf(o));
     }
+    block_amax(amax, y_amax);
 }
 
 int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,
-                        const float *abs_sum, float coef, bool accumulate) {
-    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+                        const float *abs_sum, float coef, bool accumulate, unsigned *y_amax) {
+    // (with y_amax every block ends in an atomic: fewer, longer blocks)
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, y_amax ? 512 : 256 * 16);
     if (accumulate)
-        inject_style_kernel<true><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef);
+        inject_style_kernel<true><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef, y_amax);
     else
-        inject_style_kernel<false><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef);
+        inject_style_kernel<false><<<blocks, 256, 0, s>>>(diff, sgrad, n, abs_sum, coef, y_amax);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
@@ -142,27 +161,31 @@ __global__ __launch_bounds__(256) void inject_content_kernel(float *__restrict__
                                                              const float *__restrict__ content,
                                                              ContentWindow w,
                                                              const float *__restrict__ sums,
-                                                             float coef) {
+                                                             float coef, unsigned *y_amax) {
     const size_t total = (size_t)w.C * w.fh * w.fw;
     const float scale = coef * (1.0f / (sums[1] / (float)total + kEps));
+    float amax = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int x = i % w.fw;
         const int y = (i / w.fw) % w.fh;
         const int c = i / ((size_t)w.fw * w.fh);
         const float v = scale * (feat[i] - (content ? content[content_index(w, c, y, x)] : 0.f));
-        diff[i] = ACC ? diff[i] + v : v;
+        const float o = ACC ? diff[i] + v : v;
+        diff[i] = o;
+        amax = fmaxf(amax, fabsf(o));
     }
+    block_amax(amax, y_amax);
 }
 
 int inject_content_launch(hipStream_t s, float *diff, const float *feat, const float *content,
                           const ContentWindow &win, const float *sums, float coef,
-                          bool accumulate) {
+                          bool accumulate, unsigned *y_amax) {
     const size_t total = (size_t)win.C * win.fh * win.fw;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, y_amax ? 512 : 256 * 16);
     if (accumulate)
-        inject_content_kernel<true><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef);
+        inject_content_kernel<true><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef, y_amax);
     else
-        inject_content_kernel<false><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef);
+        inject_content_kernel<false><<<blocks, 256, 0, s>>>(diff, feat, content, win, sums, coef, y_amax);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }

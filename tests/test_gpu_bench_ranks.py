@@ -73,7 +73,7 @@ def test_two_rank_bench_matches_single_process_loss():
 
 def test_farm_leg_over_two_device_entries_matches_one():
     """bench.py's `farm` sub-record (north_star's layout: one host process, TileFarm over the
-    job's GPUs) on a one-GPU box: the device list [0, 0] gives two groups of four engines on GPU 0,
+    job's GPUs) on a one-GPU box: the device list [0, 0] gives two groups of STREAMS_PER_GPU engines on GPU 0,
     eight tiles per step.  Same tiles, same arithmetic: the loss after two steps equals the
     single-entry farm's bit for bit, and the second device entry shares the first one's weights
     and targets (one copy per GPU)."""
@@ -94,8 +94,9 @@ def test_farm_leg_over_two_device_entries_matches_one():
         _, loss = job.timed(2, 1)
         assert job.timed_tile_evals == 2 * 8 and len(job.group_ms) == 2
         if len(devices) == 2:
-            assert len(job.farm.engines) == 8 and len(job.farm.primaries()) == 1
-            assert job.eng.query(lib.Q_SHARED_ENGINES) == 8
+            n_eng = 2 * bench.STREAMS_PER_GPU
+            assert len(job.farm.engines) == n_eng and len(job.farm.primaries()) == 1
+            assert job.eng.query(lib.Q_SHARED_ENGINES) == n_eng
         losses.append(loss)
         job.close()
     assert losses[0] == losses[1]

@@ -235,7 +235,7 @@ def test_farm_staged_leg_equals_direct_leg():
     sw = {l: 0.2 for l in sl}
     results = []
     for staged in (False, True):
-        farm = TileFarm(net, [0], weights, verbose=False, force_staging=staged)
+        farm = TileFarm(net, [0], weights, verbose=False, force_staging=staged, streams_per_device=4)
         np.random.seed(3)
         contents = [farm.prepare_features_device(img, cl, 64, passes=2)]
         feats = farm.prepare_features_device(style, sl, 64, passes=1)

@@ -107,7 +107,7 @@ def test_zero_copy_tiles_equal_copied_tiles():
     img = rng.uniform(-110, 120, (3, 128, 144)).astype(np.float32)
     results = []
     for zero_copy in (True, False):
-        farm = TileFarm(net, [0], weights, verbose=False)
+        farm = TileFarm(net, [0], weights, verbose=False, streams_per_device=4)     # one tile per engine
         farm.zero_copy = zero_copy
         eng = farm.master
         np.random.seed(1)
