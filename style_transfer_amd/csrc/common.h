@@ -117,6 +117,10 @@ struct ConvProblem {
     // them ignore them (conv_uses_relu_codes).
     unsigned char *in_codes = nullptr;
     const unsigned char *mask_codes = nullptr;
+    // kEpiForward with relu: out_codes (optional) receives the nibbles of the OUTPUT planes y -- the
+    // producer's epilogue holds exactly one 2x2 window per lane and channel (round 5: the fp16-split
+    // kernel and the eight-wave fp32 kernel; unsplit launches only: conv_writes_out_codes)
+    unsigned char *out_codes = nullptr;
     // the caller attaches ReLU nibbles to this launch wherever the kernel takes them (it does not under
     // STX_WINO_BIG=1, for one): launches that want them keep out of the tail split either way, so
     // that the schedule -- and with it the rounding -- does not depend on whether they were taken
@@ -203,6 +207,7 @@ struct WinoArgs {
     int pool_mode;
     unsigned char *pool_codes;   // with pool_out: window codes for the backward pass, or null
     int skip_y = 0;                             // forward + fused pooling with codes: y is not stored
+    unsigned char *out_codes = nullptr;         // forward: ReLU nibbles of y to write (ConvProblem)
     unsigned char *in_codes = nullptr;          // forward: ReLU nibbles of x to write (ConvProblem)
     const unsigned char *mask_codes = nullptr;  // backward: ReLU nibbles of the output blob to read
     long long *clock_out = nullptr;             // ConvProblem::clock_out
@@ -242,6 +247,9 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
 bool wino2_fuses_pool(const ConvProblem &p);
 // True if a launch of p under cfg writes p.in_codes (forward) / reads p.mask_codes (backward).
 bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit);
+// True if a forward launch of p under cfg writes p.out_codes (an unsplit launch of the fp16-split or the
+// eight-wave fp32 kernel; shape and epilogue only)
+bool conv_writes_out_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 int wino2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 // Tail split: a launch of n = 256 q + r work items (q >= 1) runs its last r items as r x slices K
 // slices -- one short round instead of a mostly empty full one -- and a reduce pass over those r

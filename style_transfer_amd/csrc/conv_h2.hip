@@ -348,6 +348,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const int cph = (a.H + 1) >> 1, cpw = (a.W + 1) >> 1;
     const __amdgpu_buffer_rsrc_t rmc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(a.mask_codes), 0, a.mask_codes ? a.M * cph * cpw : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t roc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_codes, 0, a.out_codes ? a.M * cph * cpw : 0, 0x00020000);
     const int M_ = a.M;
     // The lane's 2 x 2 outputs of a pass: rows yy, yy + 1 (yy = y0 + 8 pbi + 4 m + 2 (l31 >> 4)), columns
     // xx0, xx0 + 1.  Byte offsets of the four outputs in a channel plane (out of range where the
@@ -646,6 +648,15 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                     if (EPI != kEpiPartial)
                         amax = fmaxf(amax, fmaxf(lr.vo[y][0] != kOob ? fabsf(v[y].x) : 0.f,
                                                  lr.vo[y][1] != kOob ? fabsf(v[y].y) : 0.f));
+                }
+                // the ReLU sign nibble of the lane's window, for the backward pass of the layer that
+                // reads this blob: one byte instead of 16 bytes of fp32 mask per lane and channel
+                if (EPI == kEpiForward && a.out_codes) {
+                    const unsigned nib = (lr.vo[0][0] != kOob && v[0].x > 0.f ? 1u : 0u) |
+                                         (lr.vo[0][1] != kOob && v[0].y > 0.f ? 2u : 0u) |
+                                         (lr.vo[1][0] != kOob && v[1].x > 0.f ? 4u : 0u) |
+                                         (lr.vo[1][1] != kOob && v[1].y > 0.f ? 8u : 0u);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, roc, lr.vmc, (unsigned)(c * cph * cpw), 0);
                 }
                 // the lane's 2x2 outputs are one window of the 2x2/2 pooling layer that follows
                 // (pool.hip's arithmetic; ceil mode: the second row may be missing)
@@ -954,6 +965,7 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
     a.x_amax = p.x_amax;
     a.y_amax = p.y_amax;
     a.mask_codes = p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
+    a.out_codes = p.epilogue == kEpiForward && p.relu ? p.out_codes : nullptr;
     const bool inject = p.epilogue == kEpiDgrad && (p.inject.sgrad || p.inject.content);
     int n_wg = a.m_tiles * a.tiles_x * a.tiles_y;
     const bool split = ksplit > 1 && p.splitk_ws && p.splitk_ws_floats >= (size_t)ksplit * p.M * p.H * p.W;
@@ -962,6 +974,7 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
         a.y = p.splitk_ws;
         a.y_amax = nullptr;
         a.mask_codes = nullptr;        // (the reduce pass masks, from the fp32 blob)
+        a.out_codes = nullptr;         // (... and writes no nibbles: conv_writes_out_codes)
         n_wg *= ksplit;
     } else if (h2_fuses_pool(p)) {
         a.pool_out = p.pool_out;

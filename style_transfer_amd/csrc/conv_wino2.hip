@@ -516,6 +516,8 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
         const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rmc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned char *>(a.mask_codes), 0, MK ? a.M * cph * cpw : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t roc = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_codes, 0, a.out_codes ? a.M * cph * cpw : 0, 0x00020000);
     const unsigned vmc = (yy < a.H && xx0 < a.W)
                              ? (unsigned)((4 * half) * cph * cpw + (yy >> 1) * cpw + (xx0 >> 1))
                              : kOob;
@@ -720,6 +722,15 @@ __global__ __launch_bounds__(NT) void conv_wino2_kernel(WinoArgs a) {
                             amax = fmaxf(amax, fmaxf(vo[y][0] != kOob ? fabsf(v.x) : 0.f,
                                                      vo[y][1] != kOob ? fabsf(v.y) : 0.f));
                         if (EPI != kEpiForward || !a.skip_y) st2(ry_c, y, so, v, even_c);
+                    }
+                    // the ReLU sign nibble of the lane's window, for the backward pass of the layer that
+                    // reads this blob (ConvProblem::out_codes; never with the BIG variants)
+                    if (EPI == kEpiForward && !BIG && a.out_codes) {
+                        const unsigned nib = (vo[0][0] != kOob && o[0].x > 0.f ? 1u : 0u) |
+                                             (vo[0][1] != kOob && o[0].y > 0.f ? 2u : 0u) |
+                                             (vo[1][0] != kOob && o[1].x > 0.f ? 4u : 0u) |
+                                             (vo[1][1] != kOob && o[1].y > 0.f ? 8u : 0u);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, roc, vmc, (unsigned)(c * cph * cpw), 0);
                     }
                     // the lane's 2x2 outputs are exactly one window of the 2x2/2 pooling layer
                     // that follows (ceil mode: the second row may be missing): pool.hip's
@@ -974,6 +985,25 @@ bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int kspli
                                      : p.epilogue == kEpiDgrad && p.mask_codes != nullptr;
 }
 
+// The unsplit eight-wave fp32 kernel and the unsplit fp16-split kernel leave the sign nibbles of their
+// (rectified) output.  Mirrors wino2_launch / h2_launch: no K slices, no tail split, no re-based addressing.
+bool conv_writes_out_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    const char *env = getenv("STX_RELU_CODES");
+    if (env && atoi(env) == 0) return false;
+    if (p.epilogue != kEpiForward || !p.relu || !p.out_codes || ksplit > 1) return false;
+    if (cfg.id >= 300) return true;
+    if (cfg.id < 200 || cfg.id >= 210) return false;
+    const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
+    if (xb >= 2147483648.0 || yb >= 2147483648.0) return false;
+    const char *force_big = getenv("STX_WINO_BIG");
+    if (force_big && atoi(force_big) == 1) return false;
+    const bool mk = conv_uses_relu_codes(cfg, p, 1);
+    const Wino2Tail tail = wino2_tail_split(cfg, p);
+    const bool tail_taken = tail.items && p.splitk_ws &&
+                            p.splitk_ws_floats >= (size_t)tail.slices * p.M * p.H * p.W && !mk && !wino2_fuses_pool(p);
+    return !tail_taken;
+}
+
 // The forward epilogue pools only on its float2 path (even rows, 8-byte aligned arrays).
 bool wino2_fuses_pool(const ConvProblem &p) {
     return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
@@ -1052,6 +1082,9 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     a.in_codes = codes && p.epilogue == kEpiForward ? p.in_codes : nullptr;
     a.mask_codes = codes && p.epilogue == kEpiDgrad ? p.mask_codes : nullptr;
     const bool mk = a.mask_codes != nullptr || a.in_codes != nullptr;
+    // nibbles of the output: by the unsplit kernel only (conv_writes_out_codes below says the same)
+    a.out_codes = !split && !big && !(tail_ok && !mk && !wino2_fuses_pool(p)) && p.epilogue == kEpiForward && p.relu
+                      ? p.out_codes : nullptr;
     if (split) {
         a.ksplit = ksplit;
         a.y = p.splitk_ws;

@@ -79,8 +79,8 @@ struct Blob {
     DevBuf data, diff;
     DevBuf codes;             // pooled blobs: one window code per element (pool.hip), written by the
     bool codes_valid = false; // forward pass that produced `data` if its kernel can
-    DevBuf relu_codes;        // rectified blobs: sign nibbles per 2x2 window (ConvProblem::in_codes),
-    bool relu_codes_valid = false;   // written by the forward pass of the convolution that reads the blob
+    DevBuf relu_codes;        // rectified blobs: sign nibbles per 2x2 window (ConvProblem::out_codes / in_codes),
+    bool relu_codes_valid = false;   // written by the convolution that produces the blob, or by the one that reads it
     bool relu_codes_wanted = false;  // ... or would have been, had its kernel taken them (ConvProblem::wants_codes)
     // max |data| / max |diff| (or an upper bound of it) on the device, for the fp16-split convolution
     // that reads the blob (conv_h2.hip): the slot group (a blob index) of the engine's table that
@@ -572,7 +572,8 @@ static int amax_for(stx_engine *e, int blob, bool diff, const unsigned **out) {
 // `pool` (or null): the 2x2/2 pooling layer that consumes this convolution's blob; *pooled tells
 // the caller whether the convolution wrote its output too.
 int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool = nullptr,
-                     bool *pooled = nullptr, bool relu_codes = false, bool top_unobserved = false) {
+                     bool *pooled = nullptr, bool relu_codes = false, bool top_unobserved = false,
+                     bool out_codes_wanted = false) {
     const Layer &L = e->layers[li];
     Blob &b = e->blobs[L.bottom_blob];
     Blob &t = e->blobs[L.top_blob];
@@ -594,6 +595,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         if (pooled) *pooled = false;
         b.relu_codes_valid = false;
         b.relu_codes_wanted = false;
+        t.relu_codes_valid = false;
         unsigned *y_amax = nullptr;
         t.amax_data = -1;
         if (h2_enabled()) {
@@ -618,7 +620,8 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     ConvConfig cfg;
     // the fp16-split kernel where it applies (it neither writes nor reads ReLU nibbles)
     const bool h2 = h2_choice(p, &cfg);
-    b.relu_codes_wanted = !h2 && relu_codes && b.relu && b.channels <= 128;      // (see below)
+    // (a blob whose producer already left its nibbles needs none from its consumer)
+    b.relu_codes_wanted = !h2 && !b.relu_codes_valid && relu_codes && b.relu && b.channels <= 128;      // (see below)
     p.wants_codes = b.relu_codes_wanted;
     if (!h2) STX_TRY(choose_conv_config(e, li, 0, p, &cfg));
     t.amax_data = -1;
@@ -637,7 +640,6 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     // by HBM and gains 40 / 24 us from the byte masks on a 1024^2 tile, while emitting them costs
     // the forward pass 10 / 16 us; from 256 channels on the backward pass is matrix-bound, gains
     // 0-7 us and the forward pass pays 5-10: measured, profiles/r03_relu_codes_ab.txt)
-    b.relu_codes_valid = false;
     if (b.relu_codes_wanted) {
         const size_t bytes = (size_t)b.channels * ((b.h + 1) / 2) * ((b.w + 1) / 2);
         STX_TRY(b.relu_codes.ensure(bytes));
@@ -667,6 +669,20 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
         } else {
             p.pool_out = nullptr;
         }
+    }
+    // ... and the nibbles of its own (rectified) output, when a convolution reads it and its backward
+    // pass will mask with it: the epilogue holds one 2x2 window per lane and channel, so the byte
+    // costs a handful of compares -- and the consumer's backward epilogue reads 1 byte instead of
+    // 16 per lane and channel (the epilogues of one round all run at the same moment: their reads
+    // and stores are a bandwidth-bound burst)
+    t.relu_codes_valid = false;
+    // (only beside the fp16-split kernels: STX_CONV_H2=0 keeps round 4's schedule to the letter)
+    if (relu_codes && t.relu && out_codes_wanted && h2_enabled()) {
+        const size_t bytes = (size_t)t.channels * ((t.h + 1) / 2) * ((t.w + 1) / 2);
+        STX_TRY(t.relu_codes.ensure(bytes));
+        p.out_codes = static_cast<unsigned char *>(t.relu_codes.ptr);
+        t.relu_codes_valid = conv_writes_out_codes(cfg, p, conv_splitk_factor(cfg, p, true));
+        if (!t.relu_codes_valid) p.out_codes = nullptr;
     }
     ProfScope scope(e, "fwd " + L.name, conv_flops(cp.cin, cp.cout, b.h, b.w, cp.ks));
     return launch_conv(e, cfg, p);
@@ -741,7 +757,10 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
     // the maxima the fp16-split convolutions leave for each other (Blob::amax_data): none yet
     STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
     STX_HIP(hipMemsetAsync(e->amax_slots(0, false), 0, e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
-    for (Blob &b : e->blobs) b.amax_data = -1;
+    for (Blob &b : e->blobs) {
+        b.amax_data = -1;
+        b.relu_codes_valid = false;
+    }
     for (size_t li = 1; li < e->layers.size(); ++li) {
         const Layer &L = e->layers[li];
         if (L.type == STX_LAYER_RELU || !needed[L.top_blob]) continue;
@@ -770,8 +789,13 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
                     readers += e->layers[lj].type != STX_LAYER_RELU && e->layers[lj].bottom_blob == L.top_blob;
                 unobserved = readers == 1;
             }
+            // a convolution on the path reads this blob: its backward pass masks with the blob's signs
+            bool conv_reader = false;
+            for (size_t lj = li + 1; lj < e->layers.size(); ++lj)
+                conv_reader |= e->layers[lj].type == STX_LAYER_CONV && e->layers[lj].bottom_blob == L.top_blob &&
+                               needed[e->layers[lj].top_blob];
             STX_TRY(run_conv_forward(e, (int)li, L.top_blob == relu_blob, pool, &pooled, relu_codes,
-                                     unobserved));
+                                     unobserved, conv_reader));
             if (pooled) pooled_layer = pool_li;
             if (after_blob) {
                 STX_TRY((*after_blob)(L.top_blob));

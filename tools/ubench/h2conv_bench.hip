@@ -117,6 +117,17 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
     p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = backward ? 0 : 1;
     p.epilogue = backward ? kEpiDgrad : kEpiForward;
     p.x_amax = amax, p.y_amax = amax + kAmaxSlots;
+    // INJECT=1 (backward only): the style term of a tapped blob rides in the epilogue (timing only: the
+    // reference below does not add it)
+    float *sg = nullptr, *sabs = nullptr;
+    if (backward && getenv("INJECT") && atoi(getenv("INJECT"))) {
+        hipMalloc(&sg, yn * 4);
+        hipMalloc(&sabs, 4);
+        hipMemcpy(sg, mask, yn * 4, hipMemcpyDeviceToDevice);
+        const float one = 1.f * yn;
+        hipMemcpy(sabs, &one, 4, hipMemcpyHostToDevice);
+        p.inject.sgrad = sg, p.inject.s_abs_sum = sabs, p.inject.s_coef = 0.f;
+    }
     const ConvConfig cfg = mb == 3 ? h2_config(1, 2) : h2_config(mb);       // 1: 64 ch, 2: 128 ch, 3: 64 ch x two patches
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
