@@ -202,7 +202,7 @@ class FarmJob:
         loss, stats = item
         self.last_loss = float(loss)          # waits for that iteration's fences only
         stats.values()
-        self.group_ms.append(max(e.last_tile_ms() for e in self.farm.engines[:self.tiles_per_step]))
+        self.group_ms.append(group_span_ms(self.farm.engines, self.tiles_per_step))
 
     def drain(self):
         if self.in_flight is not None:
@@ -231,7 +231,7 @@ class FarmJob:
             return self.last_loss
         self.image_ops.step_stats(self.eng, avg, self.old)
         self.last_loss = float(loss)
-        self.group_ms.append(max(e.last_tile_ms() for e in self.farm.engines[:self.tiles_per_step]))
+        self.group_ms.append(group_span_ms(self.farm.engines, self.tiles_per_step))
         return self.last_loss
 
     def fence(self):
@@ -396,6 +396,15 @@ def clock_summary(engines):
     return {'mhz': float(np.median(mhz)), 'p10': float(np.percentile(mhz, 10)),
             'p90': float(np.percentile(mhz, 90)), 'min': float(np.min(mhz)), 'max': float(np.max(mhz)),
             'samples': len(mhz)}
+
+
+def group_span_ms(engines, tiles_per_step):
+    """GPU time of one step's concurrent group of tile evaluations: tile t runs on engine t mod n, the
+    tiles of one engine one after the other on its stream -- an engine with k tiles of the step
+    counts k x the HIP-event span of its newest call (stx_last_tile_ms times one call; the calls of a
+    step are alike); the longest engine is the group."""
+    n = min(len(engines), tiles_per_step)
+    return max(engines[i].last_tile_ms() * len(range(i, tiles_per_step, n)) for i in range(n))
 
 
 def add_clock(roofline, clock):
@@ -662,7 +671,10 @@ class RankJob:
                     used.append(e)
             for e in used:
                 e.sync()
-            self.group_ms.append(max(e.last_tile_ms() for e in used))
+            per_engine = {}
+            for e, _, _ in inflight:
+                per_engine[id(e)] = per_engine.get(id(e), 0) + 1
+            self.group_ms.append(max(e.last_tile_ms() * per_engine[id(e)] for e in used))
             return [(p.loss, grad_bufs[k]) for _, k, p in inflight]
 
         def cut(rect, roll):
