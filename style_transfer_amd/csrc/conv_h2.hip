@@ -4,7 +4,7 @@
 // Same job and interface as conv_wino2_kernel (forward + bias + ReLU + fused 2x2 pooling with window
 // codes, backward-to-data + ReLU mask + loss-gradient terms, split-K partials; Caffe's Convolution
 // layer as the reference drives it at style_transfer.py:566,606-610), for layers with a multiple of
-// 16 input channels.  For a pair of neighbouring outputs (x = 2t, 2t+1) of one row and the three taps
+// 32 input channels.  For a pair of neighbouring outputs (x = 2t, 2t+1) of one row and the three taps
 // g0, g1, g2 of kernel row ky:
 //     d0..d3 = in[2t-1 .. 2t+2]          (row y + ky - 1)
 //     V = [d0-d2, d1+d2, d2-d1, d1-d3]   U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
@@ -27,21 +27,26 @@
 // is small against the maximum loses relative precision only below 2^-17 of it.  The epilogue undoes
 // both scales (an exact multiplication) and leaves max |y| of its own output for the next layer.
 //
-// Work split.  A workgroup of eight waves computes 64 MB channels x (8 rows x 32 columns) = 128
-// x-tiles.  Wave (xi, h) owns transform component xi of MB 32-channel blocks for all four pixel blocks:
-// 4 MB accumulators of one 32 x 32 MFMA block.  Its A operand (the U pieces of its component and
-// channel blocks) is nobody else's, so it comes straight from global memory into registers, as ready
-// fragments (1 KB per piece and step), one chunk ahead.  The B operand (V pieces, shared by all channel
-// blocks) goes through LDS: [xi][piece][row][tile][16 channels], 40 KB, double buffered, one barrier
-// per chunk of 16 channels; a staging thread loads the four inputs of one tile for 4 channels (four
-// 16-byte loads), transforms, splits and writes eight 8-byte pieces.  Pixel block (m, s) holds rows
-// 4m + s and 4m + 2 + s of the patch, so that a lane's outputs in blocks (m, 0) and (m, 1) are the two
-// rows of one 2x2 pooling window.
+// Work split.  A workgroup of eight waves computes 64 MB channels x (8 PB rows x 32 columns) = 128 PB
+// x-tiles; three tilings (MB, PB) = (1, 1), (2, 1), (1, 2).  Wave (xi, h) owns transform component xi of
+// MB 32-channel blocks for all 4 PB pixel blocks: 4 MB PB accumulators of one 32 x 32 MFMA block.  Its A
+// operand (the U pieces of its component and channel blocks) is nobody else's, so it comes straight
+// from global memory into registers, as ready fragments (1 KB per piece and step) -- one chunk ahead
+// at (1, 1), kernel row by kernel row through two slots at the two wide tilings (128 accumulator
+// registers).  The B operand (V pieces, shared by all channel blocks) goes through LDS:
+// [xi][piece][row][tile][16 channels], 40 KB (PB = 2: 72), double buffered, one barrier per chunk of 16
+// channels; a staging thread loads the four inputs of one tile for 4 channels (four 16-byte loads),
+// transforms, splits and writes eight 8-byte pieces.  Pixel block (m, s) holds rows 4m + s and
+// 4m + 2 + s of the patch, so that a lane's outputs in blocks (m, 0) and (m, 1) are the two rows of one
+// 2x2 pooling window.
 //
 // Epilogue.  The four components of an output pair live in four waves: the accumulators of one
-// 32-channel block per wave go through LDS (128 KB per pass, MB passes); wave (hh, m, rq pair) then
-// finishes eight channels of four rows: a 2 x 2 window per lane and channel, exactly the shape
-// conv_wino2's epilogue works on.
+// 32-channel block and one 8-row patch per wave go through LDS (128 KB per pass, MB PB passes); wave
+// (hh, m, rq pair) then finishes eight channels of four rows: a 2 x 2 window per lane and channel,
+// exactly the shape conv_wino2's epilogue works on -- bias / ReLU / pooling window and its code /
+// the window's ReLU sign nibble for the consumer's backward pass (forward); mask from the fp32 blob
+// or from nibbles, loss terms (backward).  What a pass reads from memory is requested before the
+// exchange: the epilogues of a round of workgroups run at the same moment, a bandwidth-bound burst.
 
 #include <algorithm>
 #include <cstdlib>
