@@ -143,6 +143,14 @@ struct ConvProblem {
     // (optional, zeroed by the caller): where this launch leaves max |y| of its own output
     const unsigned *x_amax = nullptr;
     unsigned *y_amax = nullptr;
+    // kEpiDgrad, conv_h2.hip only (h2_takes_pooled_input): the upstream gradient arrives as the gradient
+    // of a 2x2/2 pooling layer's OUTPUT -- x is [K][ceil(H/2)][ceil(W/2)] -- together with that layer's
+    // window codes (pool.hip; the array must be readable 3 bytes past its end).  The patch staging
+    // routes / spreads it exactly as pool_bwd_codes_kernel would have: the gradient of the pooling
+    // layer's input (four times the size) is never written or read.
+    const unsigned char *pin_codes = nullptr;
+    int pin_mode = 0;            // STX_POOL_MAX / STX_POOL_AVE
+    bool pin_mask = false;       // the blob under the pooling layer is rectified (the codes carry its signs)
 #ifdef STX_EXPERIMENT_BF3
     const void *x_split = nullptr;   // tools/experiments/conv_bf3.hip only
 #endif
@@ -214,6 +222,8 @@ struct WinoArgs {
     int item_base = 0;                          // conv_wino2, K slices: first work item of the launch (tail split)
     const unsigned *x_amax = nullptr;           // conv_h2: ConvProblem::x_amax / y_amax
     unsigned *y_amax = nullptr;
+    const unsigned char *pin_codes = nullptr;   // conv_h2: ConvProblem::pin_codes / pin_mode / pin_mask
+    int pin_mode = 0, pin_mask = 0;
 #ifdef STX_EXPERIMENT_BF3
     int vp_rows = 0, vp_tp = 0;                 // tools/experiments/conv_bf3.hip only
 #endif
@@ -270,6 +280,7 @@ int h2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int tra
 int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 int h2_splitk_factor(const ConvConfig &cfg, const ConvProblem &p);
 bool h2_fuses_pool(const ConvProblem &p);
+bool h2_takes_pooled_input(const ConvConfig &cfg, const ConvProblem &p);   // ConvProblem::pin_codes
 // slots[0 .. kAmaxSlots) = 0, then max |x| as float bits into them (the largest slot counts)
 int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots);
 

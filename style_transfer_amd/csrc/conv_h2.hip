@@ -68,6 +68,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x2v __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
 constexpr int KC = 16;                      // input channels per chunk = one MFMA k-step
@@ -128,7 +129,11 @@ __device__ long long g_h2_epi[8][8];     // epilogue, pass 0: loads issued, firs
 #define STX_H2_STAMP(i)
 #endif
 
-template <int EPI, int MB, int PB>
+// PIN: the input planes arrive pooled -- the gradient of a 2x2/2 pooling layer's output plus that layer's
+// window codes (ConvProblem::pin_codes); the staging rebuilds the four inputs of an x-tile from three
+// pooled gradients and three code bytes, the arithmetic of pool_bwd_codes_kernel (pool.hip) to the bit.
+// (PIN = 1 + the pooling mode: STX_POOL_MAX / STX_POOL_AVE)
+template <int EPI, int MB, int PB, int PIN>
 __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     using G = Geo<PB>;
     constexpr int PR = G::PR, RT = G::RT, V_PIECE = G::V_PIECE, V_BYTES = G::V_BYTES, NU = G::NU, FULL = G::FULL;
@@ -164,12 +169,18 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const int m0 = mtile * BM;
     const int HW = a.H * a.W;
     const unsigned HW4 = (unsigned)HW * 4u;
+    // PIN: the pooled plane the input is given on (ceil mode)
+    const int pih = (a.H + 1) >> 1, piw = (a.W + 1) >> 1;
+    const unsigned XP4 = PIN ? (unsigned)(pih * piw) * 4u : HW4;      // bytes of one input plane
 
     constexpr unsigned kOob = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+    // (three code bytes are fetched as one dword at any byte offset: the range ends 3 bytes behind the array)
+    const __amdgpu_buffer_rsrc_t rcx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(a.pin_codes), 0, PIN ? (a.x_bytes >> 2) + 3 : 0, 0x00020000);
 
     // ---- scales: the input's from the maximum its producer left, the bank's from its header
     unsigned amax_bits = 0;
@@ -180,34 +191,144 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const float sv = pow2f(es);
     const float out_scale = pow2f(-es - ew);
 
-    // ---- staging role.  A unit = position rt of the V array x four channels (quad): 640 (PB = 2: 1152)
-    // units per chunk; every thread has units tid (and 512 + tid), the threads of waves 0 and 1 one more.
-    const bool extra = wave < 2;                          // wave-uniform
+    // ---- staging role.  The V array of a chunk has RT positions (a row of the patch, an x-tile) x 16
+    // channels.  Positions 0 .. 128 FULL - 1: a unit = one position x four channels (quad), every thread
+    // has unit tid (and 512 + tid).  The last 32 positions: one position x ONE channel per thread (32 x 16 =
+    // all 512 threads; index FULL below) -- as four-channel units they were 128, a second / third unit for
+    // the threads of waves 0 and 1 alone: sixteen registers in every wave, and the vector work of two waves
+    // half as much again as the others'.
     const bool edge = x0 == 0 || x0 + PC + 2 > a.W;       // workgroup-uniform
     unsigned xvoff[NU], v_dst[NU];
     bool left[NU], ok2[NU], ok3[NU];
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
         const int u = tid + n * NT;
-        const int quad = u & 3, rt = u >> 2;
+        const int rt = n < FULL ? u >> 2 : 128 * FULL + (tid >> 4);
+        const int ch0 = n < FULL ? (u & 3) * 4 : tid & 15;       // first (only) channel of the chunk
         const int st_r = rt / TX, st_t = rt % TX;
         const int st_y = y0 - 1 + st_r, st_x = x0 + 2 * st_t - 1;
         left[n] = st_x < 0;                                // x = -1: loaded from x = 0 and shifted
         ok2[n] = st_x + 2 < a.W, ok3[n] = st_x + 3 < a.W;
         xvoff[n] = kOob;
-        if (rt < RT && (unsigned)st_y < (unsigned)a.H && st_x + 1 < a.W)
-            xvoff[n] = (unsigned)(quad * 4 * HW + st_y * a.W + (left[n] ? 0 : st_x)) * 4u;
+        if (PIN) {
+            // columns st_x .. st_x + 3 lie in windows w0 (its right column), w0 + 1 (both), w0 + 2 (its left one)
+            const int w0 = (x0 >> 1) + st_t - 1;
+            // (the two free bits of the offset: the row's place in its window, and whether the window has two rows)
+            if ((unsigned)st_y < (unsigned)a.H && st_x + 1 < a.W)
+                xvoff[n] = (unsigned)(ch0 * pih * piw + (st_y >> 1) * piw + (left[n] ? 0 : w0)) * 4u +
+                           (unsigned)(st_y & 1) + ((st_y | 1) < a.H ? 2u : 0u);
+        } else if ((unsigned)st_y < (unsigned)a.H && st_x + 1 < a.W)
+            xvoff[n] = (unsigned)(ch0 * HW + st_y * a.W + (left[n] ? 0 : st_x)) * 4u;
         // the two 16-byte halves of a position swap places on tiles 8..15: conflict-free ds_read_b128
-        v_dst[n] = (unsigned)(rt * 32 + ((quad * 8) ^ ((st_t & 8) << 1)));
+        v_dst[n] = (unsigned)(rt * 32 + ((ch0 * 2) ^ ((st_t & 8) << 1)));
     }
 
-    f32x4 xr[NU][4];
+    f32x4 xr[FULL][4], xe;
+    // what a thread holds of one channel: the four inputs d0 .. d3 of its x-tile; PIN: three pooled
+    // gradients and (in .w: one dword, fetched at any byte offset) their three code bytes
+    auto x_fetch = [&](int n, unsigned soff) __attribute__((always_inline)) {
+        if constexpr (PIN) {
+            // (what derives from the offset is derived again at every use: hoisted out of the chunk loop it
+            // would hold a dozen registers the 128-accumulator tilings do not have)
+            unsigned xo = xvoff[n];
+            asm volatile("" : "+v"(xo));
+            const u32x3 g = __builtin_amdgcn_raw_buffer_load_b96(rx, xo & ~3u, soff, 0);
+            // (out of range stays out of range: < 2^29 bytes of codes)
+            const unsigned cw = __builtin_amdgcn_raw_buffer_load_b32(rcx, xo >> 2, soff >> 2, 0);
+            return __builtin_bit_cast(f32x4, u32x4{g.x, g.y, g.z, cw});
+        } else {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[n], soff, 0));
+        }
+    };
     auto x_load = [&](int n, int chunk) __attribute__((always_inline)) {
-        const unsigned xs = (unsigned)sgpr(chunk * KC) * HW4;
+        const unsigned xs = (unsigned)sgpr(chunk * KC) * XP4;
+        if (n == FULL) {
+            xe = x_fetch(FULL, xs);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            xr[n][i] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xvoff[n], xs + (unsigned)i * HW4, 0));
+            for (int i = 0; i < 4; ++i) xr[n][i] = x_fetch(n, xs + (unsigned)i * XP4);
+        }
+    };
+    // the border fix-up of one channel (workgroups on the left / right border only)
+    auto border = [&](f32x4 d, int n) __attribute__((always_inline)) {
+        f32x4 e;
+        e.x = left[n] ? 0.f : d.x;
+        e.y = left[n] ? d.x : d.y;
+        e.z = left[n] ? d.y : d.z;
+        e.w = left[n] ? d.z : d.w;
+        e.z = ok2[n] ? e.z : 0.f;
+        e.w = ok3[n] ? e.w : 0.f;
+        return e;
+    };
+    // PIN: the four inputs of a channel from what x_fetch brought -- pool_bwd_codes_kernel's routing (MAX:
+    // the window's gradient goes to its first maximum, if that was positive where the blob is rectified;
+    // AVE: a quarter / half / all of it to every element that was).
+    struct Unpool {
+        unsigned cmask, t_l, t_r, sh;
+        float q0;
+        bool ok4;
+    };
+    auto unpool_setup = [&](int n) __attribute__((always_inline)) {
+        Unpool r;
+        const unsigned keep = a.pin_mask ? 4u : 0u;
+        r.cmask = keep | 3u;
+        unsigned xo = xvoff[n], vd = v_dst[n];
+        asm volatile("" : "+v"(xo), "+v"(vd));             // (see x_fetch)
+        // MAX codes that select this row's left / right element; AVE: the row's first bit
+        r.sh = (xo & 1u) << 1;
+        r.t_l = keep | r.sh, r.t_r = r.t_l | 1u;
+        r.q0 = (xo & 2u) ? 0.25f : 0.5f;                               // full windows: g / 4 (exact either way)
+        r.ok4 = x0 + 2 * (int)((vd >> 5) & 15u) + 3 < a.W;             // (st_x + 4 < W; used on the border only)
+        return r;
+    };
+    auto unpool_channel = [&](f32x4 d, int n, const Unpool &r, bool fix) __attribute__((always_inline)) {
+        constexpr bool is_max = PIN == 1 + STX_POOL_MAX;
+        float g0 = d.x, g1 = d.y, g2 = d.z;
+        // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this compiler)
+        const float dw = d.w;
+        unsigned cw = __builtin_bit_cast(unsigned, dw);
+        if (fix) {                                         // x = -1: windows 0, 1, 2 were fetched
+            g2 = left[n] ? g1 : g2, g1 = left[n] ? g0 : g1;
+            cw = left[n] ? cw << 8 : cw;
+        }
+        float p0, p1, p2, p3;
+        if (is_max) {
+            const unsigned b0 = cw & r.cmask, b1 = (cw >> 8) & r.cmask, b2 = (cw >> 16) & r.cmask;
+            p0 = b0 == r.t_r ? g0 : 0.f;
+            p1 = b1 == r.t_l ? g1 : 0.f;
+            p2 = b1 == r.t_r ? g1 : 0.f;
+            p3 = b2 == r.t_l ? g2 : 0.f;
+        } else {
+            // (a window cut by the right border has one column: twice the share)
+            const float q1 = fix && !ok2[n] ? r.q0 + r.q0 : r.q0, q2 = fix && !r.ok4 ? r.q0 + r.q0 : r.q0;
+            const unsigned bits = a.pin_mask ? cw >> r.sh : 0xffffffffu;
+            p0 = (bits & 2u) ? g0 * r.q0 : 0.f;
+            p1 = (bits & 0x100u) ? g1 * q1 : 0.f;
+            p2 = (bits & 0x200u) ? g1 * q1 : 0.f;
+            p3 = (bits & 0x10000u) ? g2 * q2 : 0.f;
+        }
+        if (fix) {
+            p0 = left[n] ? 0.f : p0;
+            p2 = ok2[n] ? p2 : 0.f;
+            p3 = ok3[n] ? p3 : 0.f;
+        }
+        return f32x4{p0, p1, p2, p3};
+    };
+    auto unpool = [&](int n, bool fix) __attribute__((always_inline)) {
+        const Unpool r = unpool_setup(n);
+        if (n == FULL) {
+            xe = unpool_channel(xe, FULL, r, fix);
+            return;
+        }
+        // (channel by channel: let the scheduler interleave the four and their temporaries all live at once)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xr[n][i] = unpool_channel(xr[n][i], n, r, fix);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto component = [](f32x4 d, int c) __attribute__((always_inline)) {
+        return c == 0 ? d.x - d.z : c == 1 ? d.y + d.z : c == 2 ? d.z - d.y : d.y - d.w;
     };
     // One piece of the staging work of unit n: component c of its four channels -- four additions, the
     // split (eight v_fma_mix: hi = fp16(s v), lo = fp16(s v - hi), each ONE instruction with mixed
@@ -216,27 +337,14 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // the MFMAs; inside, a partially written register (op_sel destination) is read two instructions
     // after its last write at the earliest.
     auto piece = [&](int n, int c, char *vbuf, bool fix) __attribute__((always_inline)) {
-        if (c == 0 && fix) {
-            asm volatile("");      // (a scalar branch: workgroups on the left / right border only)
+        if (!PIN && c == 0 && fix) {
+            asm volatile("");      // (a scalar branch)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 d = xr[n][i];
-                f32x4 e;
-                e.x = left[n] ? 0.f : d.x;
-                e.y = left[n] ? d.x : d.y;
-                e.z = left[n] ? d.y : d.z;
-                e.w = left[n] ? d.z : d.w;
-                e.z = ok2[n] ? e.z : 0.f;
-                e.w = ok3[n] ? e.w : 0.f;
-                xr[n][i] = e;
-            }
+            for (int i = 0; i < 4; ++i) xr[n][i] = border(xr[n][i], n);
         }
         float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 d = xr[n][i];
-            v[i] = c == 0 ? d.x - d.z : c == 1 ? d.y + d.z : c == 2 ? d.z - d.y : d.y - d.w;
-        }
+        for (int i = 0; i < 4; ++i) v[i] = component(xr[n][i], c);
         unsigned h0, h1, l0, l1;
         if (STX_H2_SKIP & 64) {       // (timing experiment: the LDS writes without the vector work)
             h0 = __builtin_bit_cast(unsigned, v[0]), h1 = __builtin_bit_cast(unsigned, v[1]);
@@ -260,10 +368,41 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 0) * V_PIECE) = u32x2v{h0, h1};
         *reinterpret_cast<u32x2v *>(vbuf + v_dst[n] + (c * 2 + 1) * V_PIECE) = u32x2v{l0, l1};
     };
+    // ... and of the single-channel item: components c and c + 1 (c = 0, 2) -- two additions, four
+    // v_fma_mixlo and four 2-byte writes.
+    auto piece_one = [&](int c, char *vbuf, bool fix) __attribute__((always_inline)) {
+        if (!PIN && c == 0 && fix) {
+            asm volatile("");
+            xe = border(xe, FULL);
+        }
+        const float va = component(xe, c), vb = component(xe, c + 1);
+        unsigned ha, hb, la, lb;
+        asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+            "v_fma_mixlo_f16 %1, %5, %6, 0\n\t"
+            "v_fma_mixlo_f16 %2, %4, %6, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %3, %5, %6, -%1 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+            : "=&v"(ha), "=&v"(hb), "=&v"(la), "=&v"(lb)
+            : "v"(va), "v"(vb), "v"(sv));
+        if (STX_H2_SKIP & 32) {
+            asm volatile("" :: "v"(ha), "v"(hb), "v"(la), "v"(lb));
+            return;
+        }
+        char *dst = vbuf + v_dst[FULL];
+        *reinterpret_cast<unsigned short *>(dst + (c * 2 + 0) * V_PIECE) = (unsigned short)ha;
+        *reinterpret_cast<unsigned short *>(dst + (c * 2 + 1) * V_PIECE) = (unsigned short)la;
+        *reinterpret_cast<unsigned short *>(dst + (c * 2 + 2) * V_PIECE) = (unsigned short)hb;
+        *reinterpret_cast<unsigned short *>(dst + (c * 2 + 3) * V_PIECE) = (unsigned short)lb;
+    };
     auto stage_all = [&](int n, int buf) __attribute__((always_inline)) {
         char *vbuf = ldsb + buf * V_BYTES;
+        if (PIN) unpool(n, edge);
+        if (n == FULL) {
+            piece_one(0, vbuf, edge);
+            piece_one(2, vbuf, edge);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) piece(n, c, vbuf, edge);
+            for (int c = 0; c < 4; ++c) piece(n, c, vbuf, edge);
+        }
     };
 
     // ---- A operand: fragments of (xi, channel block), [ky][block][piece], straight from the packed bank
@@ -305,9 +444,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     };
 
     // ---- prologue
-#pragma unroll
-    for (int n = 0; n < FULL; ++n) x_load(n, c_begin);
-    if (extra) x_load(FULL, c_begin);
+    static_for<0, NU>([&](auto n_c) __attribute__((always_inline)) { x_load(decltype(n_c)::value, c_begin); });
     if (LEAN) {
         a_load(0, 0, c_begin);
     } else {
@@ -380,7 +517,10 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         r.vmc = in ? (unsigned)((4 * half) * cph * cpw + (r.yy >> 1) * cpw + (xx0 >> 1)) : kOob;
         return r;
     };
-    const LaneRows rows0 = lane_rows(0);
+    // (hoisted: a thousand cycles under the first loads' latency -- except where the registers are not there)
+    constexpr bool HOIST = !(PIN && PB == 2);
+    LaneRows rows0{};
+    if (HOIST) rows0 = lane_rows(0);
     auto ld2 = [&](const __amdgpu_buffer_rsrc_t &rs, const LaneRows &lr, int y, unsigned so, auto even_c)
                    __attribute__((always_inline)) {
         if (decltype(even_c)::value)
@@ -405,24 +545,23 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         }
     };
     int ccol[2] = {0, 0};
-    if (EPI == kEpiDgradInject && content) {
+    auto content_columns = [&](const LaneRows &lr) __attribute__((always_inline)) {
+        if (EPI == kEpiDgradInject && content) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const bool ok = rows0.yy < a.H && xx0 < a.W;
-            const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
-            int r = (cw_ox + x) % cw_cw;
-            ccol[e] = r < 0 ? r + cw_cw : r;
+            for (int e = 0; e < 2; ++e) {
+                const bool ok = lr.yy < a.H && xx0 < a.W;
+                const int x = ok ? (xx0 + e < a.W ? xx0 + e : xx0) : (e && 1 < a.W ? 1 : 0);
+                int r = (cw_ox + x) % cw_cw;
+                ccol[e] = r < 0 ? r + cw_cw : r;
+            }
         }
-    }
-#pragma unroll
-    for (int n = 0; n < FULL; ++n) {
+    };
+    if (HOIST) content_columns(rows0);
+    static_for<0, NU>([&](auto n_c) __attribute__((always_inline)) {
+        constexpr int n = decltype(n_c)::value;
         stage_all(n, 0);
         if (c_begin + 1 < c_end) x_load(n, c_begin + 1);
-    }
-    if (extra) {
-        stage_all(FULL, 0);
-        if (c_begin + 1 < c_end) x_load(FULL, c_begin + 1);
-    }
+    });
     lds_barrier();
     b_read(0, 0, 0);
 
@@ -432,18 +571,18 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     // The staging pieces are dealt out behind the MFMAs; sched_barrier pins the order.
     constexpr int NBLK = 3 * NJ;                                     // blocks of a chunk: 12 / 24
     constexpr int PER_BLK = 3 * MB, SLOTS = (NBLK - 1) * PER_BLK;    // slots in front of the barrier
-    // unit 0's four pieces (one component each) sit behind slots 1, 1 + 2 STEP, ...; unit 1's (waves 0
-    // and 1 only: a uniform branch) between them.  (All of unit 0 first, unit 1 behind it, so that each
-    // unit's registers can be asked for again three quarters of a chunk ahead: 5350 -> 5720 cycles per
-    // chunk -- the vector work wants to be spread evenly.)
-    constexpr int NP = 4 * NU;                                       // staging pieces: unit k % NU, component k / NU
+    // Staging pieces k = 0 .. NP - 1 sit behind slots 1, 1 + STEP, ...: piece k / NU of unit k % NU, the
+    // units' pieces interleaved.  (All of unit 0 first, unit 1 behind it, so that each unit's registers can
+    // be asked for again three quarters of a chunk ahead: 5350 -> 5720 cycles per chunk -- the vector work
+    // wants to be spread evenly.)  A four-channel unit has four pieces, one component each (PIN: five, the
+    // un-pooling first); the single-channel item two, two components each (PIN: three).
+    constexpr int NQ = PIN ? 5 : 4, NQ1 = PIN ? 3 : 2;
+    constexpr int NP = NQ * NU;
     constexpr int STEP = (SLOTS - 2) / NP;
-#ifdef STX_H2_NO_BRANCH       // (timing experiment: no second unit, no border fix-up -- wrong results)
-    const bool two = false, edge_fix = false;
-    (void)extra;
+#ifdef STX_H2_NO_BRANCH       // (timing experiment: no border fix-up -- wrong results)
+    const bool edge_fix = false;
 #else
     const bool edge_fix = edge;
-    const bool two = extra;
 #endif
     auto run_chunk = [&](auto buf_c, int chunk, auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
@@ -474,18 +613,16 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 }
                 if (MORE && !(STX_H2_SKIP & 1) && s >= 1 && (s - 1) % STEP == 0) {
                     constexpr int k = (s - 1) / STEP;             // 0 .. NP - 1
-                    if (k < NP && k % NU < FULL) {
-                        piece(k % NU, k / NU, vnext, edge_fix);
-                    } else if (k < NP && two) {
-                        asm volatile("");                         // (keeps this a scalar branch)
-                        piece(FULL, k / NU, vnext, edge_fix);
-                    }
+                    constexpr int n = k % NU, q = k / NU;
+                    if (k < NP && PIN && q == 0) unpool(n, edge_fix);
+                    else if (k < NP && n < FULL) piece(n, q - (PIN ? 1 : 0), vnext, edge_fix);
+                    else if (k < NP && q < NQ1) piece_one(2 * (q - (PIN ? 1 : 0)), vnext, edge_fix);
                 }
                 if (MORE && !(STX_H2_SKIP & 4)) {
                     // (a unit's registers are asked for again right behind its last piece)
                     static_for<0, NU>([&](auto u_c) __attribute__((always_inline)) {
                         constexpr int u = decltype(u_c)::value;
-                        if (s == 1 + (3 * NU + u) * STEP + 1 && (u < FULL || two) && chunk + 2 < c_end)
+                        if (s == 1 + (((u < FULL ? NQ : NQ1) - 1) * NU + u) * STEP + 1 && chunk + 2 < c_end)
                             x_load(u, chunk + 2);
                     });
                 }
@@ -543,7 +680,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     auto epilogue_pass = [&](auto pass_c, auto even_c) __attribute__((always_inline)) {
         constexpr int pass = decltype(pass_c)::value;
         constexpr int mbi = pass % MB, pbi = pass / MB;        // channel block of the wave, patch of the stack
-        const LaneRows lr = pbi == 0 ? rows0 : lane_rows(pbi);
+        const LaneRows lr = pbi == 0 && HOIST ? rows0 : lane_rows(pbi);
+        if (!HOIST && pass == 0) content_columns(lr);
         int crow[2] = {0, 0};                                  // common.h: content_index, once per lane and pass
         if (EPI == kEpiDgradInject && content) {
 #pragma unroll
@@ -917,14 +1055,20 @@ ConvConfig h2_pick_config(const ConvProblem &p) {
     return best;
 }
 
+// A backward launch that can take its input pooled (ConvProblem::pin_codes): unsplit ones -- the K slices
+// of a split launch would each un-pool the same patch again, and the planes that split are small.
+bool h2_takes_pooled_input(const ConvConfig &cfg, const ConvProblem &p) {
+    return cfg.id >= 300 && p.epilogue == kEpiDgrad && h2_usable(p) && h2_splitk_factor(cfg, p) == 1;
+}
+
 bool h2_fuses_pool(const ConvProblem &p) {
     return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
            (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
-template <int EPI, int MB, int PB>
+template <int EPI, int MB, int PB, int PIN = 0>
 static int h2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
-    auto kern = conv_h2_kernel<EPI, MB, PB>;
+    auto kern = conv_h2_kernel<EPI, MB, PB, PIN>;
     constexpr size_t kLdsBytes = Geo<PB>::kLds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
@@ -965,6 +1109,17 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
     a.pool_codes = nullptr;
     a.pool_mode = p.pool_mode;
     a.x_bytes = (int)(4.0 * p.K * (double)p.H * p.W);
+    const bool pin = p.pin_codes != nullptr;
+    if (pin) {
+        if (!h2_takes_pooled_input(cfg, p) || ksplit > 1) {
+            set_error("h2_launch: a pooled input goes with unsplit backward launches only");
+            return STX_ERR_UNSUPPORTED;
+        }
+        a.x_bytes = (int)(4.0 * p.K * (double)((p.H + 1) / 2) * ((p.W + 1) / 2));
+        a.pin_codes = p.pin_codes;
+        a.pin_mode = p.pin_mode;
+        a.pin_mask = p.pin_mask ? 1 : 0;
+    }
     a.w_bytes = (int)(4 * (h2_packed_floats(p.K, p.M) - kHeaderFloats));
     a.clock_out = p.clock_out;
     a.x_amax = p.x_amax;
@@ -993,6 +1148,27 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
                 : cfg.id == 302 ? (h2_launch_epi<E, 1, 2>(s, a, n_wg))                   \
                                 : (h2_launch_epi<E, 1, 1>(s, a, n_wg)));                 \
         break;
+#define STX_H2_PIN_CASE(E, P)                                                            \
+    case E:                                                                              \
+        STX_TRY(cfg.id == 301   ? (h2_launch_epi<E, 2, 1, P>(s, a, n_wg))                \
+                : cfg.id == 302 ? (h2_launch_epi<E, 1, 2, P>(s, a, n_wg))                \
+                                : (h2_launch_epi<E, 1, 1, P>(s, a, n_wg)));              \
+        break;
+    if (pin && p.pin_mode == STX_POOL_MAX) {
+        switch (epi) {
+            STX_H2_PIN_CASE(kEpiDgrad, 1 + STX_POOL_MAX)
+            STX_H2_PIN_CASE(kEpiDgradInject, 1 + STX_POOL_MAX)
+        }
+        return STX_OK;
+    }
+    if (pin) {
+        switch (epi) {
+            STX_H2_PIN_CASE(kEpiDgrad, 1 + STX_POOL_AVE)
+            STX_H2_PIN_CASE(kEpiDgradInject, 1 + STX_POOL_AVE)
+        }
+        return STX_OK;
+    }
+#undef STX_H2_PIN_CASE
     switch (epi) {
         STX_H2_CASE(kEpiForward)
         STX_H2_CASE(kEpiDgrad)

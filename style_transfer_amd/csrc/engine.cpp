@@ -658,7 +658,7 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
             *pooled = true;
             pt.amax_data = t.amax_data;    // max (or mean) of 2x2 windows: the same bound
             if (conv_writes_pool_codes(cfg) && e->pool_codes) {
-                STX_TRY(pt.codes.ensure(pt.count()));
+                STX_TRY(pt.codes.ensure(pt.count() + 4));    // (+ 4: conv_h2.hip fetches three codes as one dword)
                 p.pool_codes = static_cast<unsigned char *>(pt.codes.ptr);
                 pt.codes_valid = true;
                 // the full-resolution blob is then dead weight unless somebody looks at it: the
@@ -688,7 +688,36 @@ int run_conv_forward(stx_engine *e, int li, bool force_relu, const Layer *pool =
     return launch_conv(e, cfg, p);
 }
 
-int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused) {
+// The backward problem of convolution layer li, as far as the choice of kernel depends on it.
+static ConvProblem conv_backward_shape(stx_engine *e, int li) {
+    const Layer &L = e->layers[li];
+    const Blob &b = e->blobs[L.bottom_blob];
+    const ConvParams &cp = e->sh->conv[li];
+    ConvProblem p{};
+    p.K = cp.cout;
+    p.M = cp.cin;
+    p.H = b.h;
+    p.W = b.w;
+    p.ksize = cp.ks;
+    p.epilogue = kEpiDgrad;
+    return p;
+}
+
+// Can the backward pass of convolution li take the gradient of the 2x2/2 pooling layer behind it as it
+// stands -- pooled, with the window codes -- and route it inside its own patch staging (conv_h2.hip, PIN)?
+// Then the pooling layer's backward kernel does not run, and the gradient of the convolution's output
+// blob (four times the pooled one) is neither written nor read.  STX_POOL_BWD_FUSE=0 keeps the kernel.
+static bool conv_backward_takes_pooled(stx_engine *e, int li) {
+    const char *env = getenv("STX_POOL_BWD_FUSE");
+    if (env && atoi(env) == 0) return false;
+    const ConvProblem p = conv_backward_shape(e, li);
+    ConvConfig cfg;
+    return p.ksize == 3 && p.M > 4 && h2_choice(p, &cfg) && h2_takes_pooled_input(cfg, p);
+}
+
+// `pooled` (or null): the pooling layer behind this convolution whose backward pass the caller skipped
+// (conv_backward_takes_pooled): the incoming gradient is that of the pooled blob.
+int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused, const Layer *pooled = nullptr) {
     const Layer &L = e->layers[li];
     Blob &b = e->blobs[L.bottom_blob];
     const Blob &t = e->blobs[L.top_blob];
@@ -732,7 +761,20 @@ int run_conv_backward(stx_engine *e, int li, const ConvInject *inj, bool *fused)
     if (fused) *fused = inj && can_fuse;
     if (inj && can_fuse) p.inject = *inj;
     b.amax_diff = -1;
-    if (h2) STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
+    if (pooled) {
+        const Blob &pt = e->blobs[pooled->top_blob];
+        if (!h2 || !h2_takes_pooled_input(cfg, p) || !pt.codes_valid) {
+            set_error("run_conv_backward: %s cannot take the gradient of %s pooled", L.name.c_str(), pt.name.c_str());
+            return STX_ERR_UNSUPPORTED;
+        }
+        p.x = pt.diff.f();
+        p.pin_codes = static_cast<const unsigned char *>(pt.codes.ptr);
+        p.pin_mode = pooled->pool_mode;
+        p.pin_mask = t.relu;
+        STX_TRY(amax_for(e, pooled->top_blob, true, &p.x_amax));    // (routing / averaging never raises the maximum)
+    } else if (h2) {
+        STX_TRY(amax_for(e, L.top_blob, true, &p.x_amax));
+    }
     if (h2 || (cfg.id >= 200 && cfg.id < 210 && h2_enabled())) {
         p.y_amax = e->amax_slots(L.bottom_blob, true);
         b.amax_diff = L.bottom_blob;
@@ -809,7 +851,7 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
                 unsigned char *codes = nullptr;
                 t.codes_valid = false;
                 if (e->pool_codes) {
-                    STX_TRY(t.codes.ensure(t.count()));
+                    STX_TRY(t.codes.ensure(t.count() + 4));      // (see run_conv_forward)
                     codes = static_cast<unsigned char *>(t.codes.ptr);
                     t.codes_valid = true;
                 }
@@ -1745,6 +1787,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             STX_HIP(hipMemsetAsync(e->blobs[cur].diff.ptr, 0, e->blobs[cur].count() * sizeof(float),
                                    e->stream));
     }
+    const Layer *pooled = nullptr;      // a pooling layer whose backward pass rides in the next convolution's
     while (cur != data_blob) {
         const int li = e->blobs[cur].producer;
         const Layer &L = e->layers[li];
@@ -1752,6 +1795,14 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         const Blob &top = e->blobs[cur];
         const int k = tap_of[L.bottom_blob];
         bool fused = false;
+        if (L.type == STX_LAYER_POOL && top.codes_valid && k < 0 && L.ksize == 2 && L.stride == 2 && L.pad == 0 &&
+            e->layers[bot.producer].type == STX_LAYER_CONV && conv_backward_takes_pooled(e, bot.producer)) {
+            // the convolution under the pooling layer un-pools inside its patch staging: nothing to launch,
+            // the gradient of `bot` never exists (nobody else wants it: no loss term taps that blob)
+            pooled = &L;
+            cur = L.bottom_blob;
+            continue;
+        }
         if (L.type == STX_LAYER_CONV) {
             ConvInject inj{};
             if (k >= 0 && fusable((size_t)k)) {
@@ -1770,7 +1821,8 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 }
                 fused = true;
             }
-            STX_TRY(run_conv_backward(e, li, fused ? &inj : nullptr, &fused));
+            STX_TRY(run_conv_backward(e, li, fused ? &inj : nullptr, &fused, pooled));
+            pooled = nullptr;
         } else {
             ProfScope scope(e, "bwd " + L.name, 0.0);
             if (top.codes_valid)

@@ -224,3 +224,44 @@ def test_first_layer_kernel_with_its_own_gram_partials(model, th, tw, monkeypatc
     assert np.array_equal(out['0'][2], out['1'][2])
     assert out['1'][0] == pytest.approx(out['0'][0], rel=1e-6)
     assert np.abs(out['0'][1] - out['1'][1]).max() <= 1e-5 * np.abs(out['0'][1]).max()
+
+
+@pytest.mark.parametrize('model,th,tw', [('vgg19', 256, 384), ('vgg19', 203, 331), ('vgg16_avgpool', 256, 320),
+                                         ('vgg16_avgpool', 131, 277), ('vgg19', 64, 96)])
+def test_pooling_backward_inside_the_next_convolution(model, th, tw, monkeypatch):
+    """The backward pass of a convolution that sits under a 2x2/2 pooling layer takes the POOLED gradient
+    and the window codes and routes it inside its own patch staging (conv_h2.hip, PIN): the pooling
+    layer's backward kernel does not run and the four-times-larger gradient of the convolution's output
+    is never written.  Same numbers into the same arithmetic: against STX_POOL_BWD_FUSE=0 (the stand-alone
+    kernel, pool.hip -- held to the oracle by every other test here) the gradient is BIT-IDENTICAL, on
+    MAX and AVE nets, even and odd planes (windows cut by the right / bottom border)."""
+    from style_transfer_amd.engine import TileEngine
+    from tests.gpu_helpers import builtin_net, require_gpu, synthetic_weights
+    require_gpu()
+    net = builtin_net(model)
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(th)
+    tile = rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)
+    cl, sl = ['conv4_2'], ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+    cw, sw = {'conv4_2': 0.05}, {l: 0.2 for l in sl}
+    out, skipped = {}, {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('STX_POOL_BWD_FUSE', fuse)
+        eng = TileEngine(net, 0, weights)
+        r = np.random.RandomState(3)
+        eng.set_contents_and_styles(
+            [{l: np.abs(r.standard_normal(eng.feature_shape(l, th, tw))).astype(np.float32) for l in cl}],
+            [{l: np.tril(r.standard_normal((eng.layer_info(l)[1],) * 2)).astype(np.float32) for l in sl}])
+        eng.profile(True)
+        out[fuse] = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        labels = [row[0] for row in eng.profile_read()]
+        skipped[fuse] = 4 - sum(l.startswith('bwd pool') for l in labels)
+        eng.profile(False)
+        again = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        assert again[0] == out[fuse][0] and np.array_equal(again[1], out[fuse][1])
+        eng.close()
+    assert skipped['0'] == 0
+    # (the small planes of the deep layers split their reduction and keep the stand-alone kernel)
+    assert skipped['1'] >= (1 if th * tw < 10000 else 2), skipped
+    assert out['1'][0] == out['0'][0]
+    assert np.array_equal(out['1'][1], out['0'][1])

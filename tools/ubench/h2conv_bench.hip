@@ -99,6 +99,45 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
             h[i] = gscale * 0.1f * g * std::exp(1.5f * (rnd() + rnd() + rnd() + rnd() - 2.f) * 1.7f);
         }
     }
+    // PIN=1 (MAX) / 2 (AVE), backward only: the gradient arrives pooled, with window codes (PINMASK=0: the
+    // blob under the pooling layer is not rectified); x = what pool_bwd_codes_kernel would have written
+    const int pin = backward && getenv("PIN") ? atoi(getenv("PIN")) : 0;
+    const bool pin_mask = !getenv("PINMASK") || atoi(getenv("PINMASK"));
+    const int ph = (H + 1) / 2, pw = (W + 1) / 2;
+    float *dyp = nullptr;
+    unsigned char *codes = nullptr;
+    if (pin) {
+        std::vector<float> dy((size_t)K * ph * pw);
+        std::vector<unsigned char> cd(dy.size() + 4, 0);
+        for (size_t i = 0; i < dy.size(); ++i) {
+            dy[i] = h[i];
+            cd[i] = (unsigned char)(rnd() * (pin == 1 ? 8.f : 16.f));
+        }
+        for (int k = 0; k < K; ++k)
+            for (int oy = 0; oy < ph; ++oy)
+                for (int ox = 0; ox < pw; ++ox) {
+                    const size_t i = ((size_t)k * ph + oy) * pw + ox;
+                    const bool hx = 2 * ox + 1 < W, hy = 2 * oy + 1 < H;
+                    const float g = dy[i];
+                    const unsigned code = cd[i];
+                    float o[4];
+                    if (pin == 1) {
+                        const float gs = (!pin_mask || (code & 4u)) ? g : 0.f;
+                        for (int e = 0; e < 4; ++e) o[e] = (code & 3u) == (unsigned)e ? gs : 0.f;
+                    } else {
+                        const float gq = g / ((hx ? 2.f : 1.f) * (hy ? 2.f : 1.f));
+                        for (int e = 0; e < 4; ++e) o[e] = (!pin_mask || (code >> e & 1u)) ? gq : 0.f;
+                    }
+                    for (int e = 0; e < 4; ++e) {
+                        const int yy = 2 * oy + (e >> 1), xx = 2 * ox + (e & 1);
+                        if (yy < H && xx < W) h[((size_t)k * H + yy) * W + xx] = o[e];
+                    }
+                }
+        hipMalloc(&dyp, dy.size() * 4);
+        hipMalloc(&codes, cd.size());
+        hipMemcpy(dyp, dy.data(), dy.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(codes, cd.data(), cd.size(), hipMemcpyHostToDevice);
+    }
     hipMemcpy(x, h.data(), xn * 4, hipMemcpyHostToDevice);
     const float ws = std::sqrt(2.f / (9.f * K));
     for (size_t i = 0; i < wn; ++i) h[i] = (rnd() + rnd() + rnd() + rnd() - 2.f) * 1.7f * ws;
@@ -111,7 +150,7 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
     // forward: w is [M][K][3][3]; backward: the layer's bank is [Mo = K][Ko = M] and the kernel's
     // output channels are the layer's inputs
     if (h2_pack_weights(0, w, backward ? K : M, backward ? M : K, backward, packed) != 0) return;
-    if (absmax_launch(0, x, xn, amax) != 0) return;
+    if (absmax_launch(0, pin ? dyp : x, pin ? (size_t)K * ph * pw : xn, amax) != 0) return;
     ConvProblem p{};
     p.x = x, p.w = packed, p.y = y, p.bias = backward ? nullptr : bias, p.mask = backward ? mask : nullptr;
     p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = backward ? 0 : 1;
@@ -128,6 +167,7 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
         hipMemcpy(sabs, &one, 4, hipMemcpyHostToDevice);
         p.inject.sgrad = sg, p.inject.s_abs_sum = sabs, p.inject.s_coef = 0.f;
     }
+    if (pin) p.x = dyp, p.pin_codes = codes, p.pin_mode = pin == 1 ? STX_POOL_MAX : STX_POOL_AVE, p.pin_mask = pin_mask;
     const ConvConfig cfg = mb == 3 ? h2_config(1, 2) : h2_config(mb);       // 1: 64 ch, 2: 128 ch, 3: 64 ch x two patches
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -173,6 +213,7 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
     for (size_t i = 0; i < yn; ++i) ymax = std::max(ymax, std::fabs(yh[i]));
     for (int i = 0; i < kAmaxSlots; ++i) kmax = std::max(kmax, *reinterpret_cast<float *>(&ah[kAmaxSlots + i]));
     const double flop = 2.0 * M * K * 9 * H * W;
+    if (pin) printf("(pooled input, %s%s) ", pin == 1 ? "MAX" : "AVE", pin_mask ? ", rectified" : "");
     printf("%s K %4d M %4d %4dx%-4d MB %d: %.3f ms  %.1f TFLOP/s (direct-equivalent)  err %.2e of max (%zu bad)  max |y| %s (%g / %g)\n",
            backward ? "bwd" : "fwd", K, M, H, W, mb, ms, flop / ms / 1e9, max_err / max_ref, bad,
            ymax == kmax ? "ok" : "WRONG", kmax, ymax);
