@@ -29,3 +29,41 @@ def make_oracle(model_name, seed=0):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+MEAN_BGR = np.float32([103.939, 116.779, 123.68])
+
+
+def raw_to_u8(raw):
+    """The reference's picture of a mean-subtracted BGR array (style_transfer.py: deprocess): add the
+    mean, BGR -> RGB, clip, truncate.  Pinned on the fixture's own (final_raw, final_u8) pair by
+    tests/test_oracle_golden.py."""
+    x = raw + MEAN_BGR[:, None, None]
+    return np.uint8(np.clip(x[::-1].transpose(1, 2, 0), 0, 255))
+
+
+def cfg4_reference_branches(golden):
+    """The reference's own trajectories on the config-4 miniature (make_golden.py section 4c): the
+    committed run, and the runs of the same reference code with its convolutions rounded as any other
+    float32 kernel rounds them (tests/golden/cfg4_sensitivity.py -> cfg4_branches.npz: the trajectory
+    branches at ReLU / max-pooling near-ties of its 30 x 33-pixel tiles, half of the runs leave the
+    committed one by 5.6e-4 at the second step).  [{log [5][4], final_raw, final_u8, runs}], the
+    committed run first."""
+    import os
+    out = [dict(log=np.float64(golden['e2e_cfg4.log']), final_raw=golden['e2e_cfg4.final_raw'],
+                final_u8=golden['e2e_cfg4.final_u8'], runs=1)]
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cfg4_branches.npz'))
+    for log, raw, runs in zip(d['logs'], d['final_raw'], d['runs']):
+        if np.allclose(log[:, 2], out[0]['log'][:, 2], rtol=2e-4):
+            out[0]['runs'] += int(runs)
+        else:
+            out.append(dict(log=log, final_raw=raw, final_u8=raw_to_u8(raw), runs=int(runs)))
+    return out
+
+
+def matching_branch(branches, losses, rtol=2e-4):
+    """The reference trajectory whose losses `losses` follows step by step to rtol (None: none of them)."""
+    for b in branches:
+        if len(losses) == len(b['log']) and np.allclose(losses, b['log'][:, 2], rtol=rtol):
+            return b
+    return None

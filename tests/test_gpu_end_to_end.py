@@ -204,14 +204,25 @@ def test_config4_miniature_matches_reference_run(golden):
                            [Image.fromarray(golden['e2e_cfg4.style_u8'])],
                            callback=lambda **kw: log.append(
                                (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
-    ref, got = golden['e2e_cfg4.log'], np.float64(log)
-    print(got[:, 2] / ref[:, 2] - 1)
-    assert got.shape == ref.shape
-    assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
+    # The reference's trajectory on this fixture BRANCHES when its convolutions are rounded as any other
+    # float32 kernel rounds them (tests/golden/cfg4_sensitivity.py: half of the reference's own runs leave
+    # the committed log by 5.6e-4 at the second step -- tiles of 30 x 33 pixels, one near-tie moves the
+    # objective by 1e-3): the run must follow ONE of the reference's branches, to the fixture's 2e-4.
+    from tests.helpers import cfg4_reference_branches, matching_branch
+    got = np.float64(log)
+    branches = cfg4_reference_branches(golden)
+    print([np.array2string(got[:, 2] / b['log'][:, 2] - 1, precision=2) for b in branches])
+    assert got.shape == branches[0]['log'].shape
+    br = matching_branch(branches, got[:, 2])
+    assert br is not None, (got[:, 2], [b['log'][:, 2] for b in branches])
+    ref = br['log']
     assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
     assert np.allclose(got[:, 3], ref[:, 3], rtol=2e-3)
-    diff = np.abs(st.current_raw.get() - golden['e2e_cfg4.final_raw'])
-    print('final image: max %.4f mean %.6f' % (diff.max(), diff.mean()))
+    # (the last line search flips on its own: the unperturbed reference repeated differs from itself by
+    # 0.06 .. 0.9 in the final picture)
+    diff = np.abs(st.current_raw.get() - br['final_raw'])
+    print('final image: max %.4f mean %.6f (branch taken by %d of the reference\'s runs)'
+          % (diff.max(), diff.mean(), br['runs']))
     assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
     # 4 tiles x (3 + 1) evaluations at the first scale, 9 tiles x (2 + 1) at the second
     assert farm.tile_evals == 4 * (3 + 1) + 9 * (2 + 1)

@@ -109,3 +109,20 @@ def test_regularizers_are_additive(golden):
     p_l, p_g = num_ops.p_norm_loss_grad((img + mean - np.float32(127.5)) / np.float32(127.5), 6.0)
     assert loss == pytest.approx(5 * tv_l + 2 * p_l, rel=1e-6)
     assert rel_err(grad, 5 * tv_g + 2 * p_g) < 1e-6
+
+
+def test_config4_miniature_branches_of_the_reference(golden):
+    """tests/golden/cfg4_branches.npz (tests/golden/cfg4_sensitivity.py: the reference's own code on the
+    config-4 miniature with its convolutions rounded as another float32 kernel rounds them): the first
+    branch IS the committed fixture's trajectory, the others leave it by more than the 2e-4 band from the
+    second step on, and start from the same objective; the picture of a raw array is the reference's."""
+    from tests.helpers import cfg4_reference_branches, matching_branch, raw_to_u8
+    assert np.array_equal(raw_to_u8(golden['e2e_cfg4.final_raw']), golden['e2e_cfg4.final_u8'])
+    branches = cfg4_reference_branches(golden)
+    assert len(branches) >= 2 and sum(b['runs'] for b in branches) >= 10
+    assert branches[0]['runs'] >= 3                  # the committed trajectory is one the perturbed runs take too
+    assert matching_branch(branches, golden['e2e_cfg4.log'][:, 2]) is branches[0]
+    for b in branches[1:]:
+        assert b['log'].shape == branches[0]['log'].shape and b['final_raw'].shape == branches[0]['final_raw'].shape
+        rel = np.abs(b['log'][:, 2] / branches[0]['log'][:, 2] - 1)
+        assert rel[0] < 1e-6 and rel[1:].max() > 2e-4 and rel.max() < 1e-2
