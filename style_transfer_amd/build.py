@@ -49,7 +49,7 @@ def _compile(src, extra, force):
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
     deps = [path, os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bf16x3.h'),
-            os.path.join(INCLUDE, 'stx.h')]
+            os.path.join(CSRC, 'f16x2.h'), os.path.join(INCLUDE, 'stx.h')]
     if force or _stale(obj, deps):
         cmd = [HIPCC] + COMMON + extra + ['-c', path, '-o', obj]
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

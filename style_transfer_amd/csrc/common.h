@@ -313,15 +313,23 @@ struct GramPlan {
     size_t partial_floats;
 };
 GramPlan gram_plan(int C, int HW);
-int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials);
+// f_amax (or null): kAmaxSlots words of float bits bounding |feat| -> the fp16 two-piece kernel
+// (f16x2.h; ask gram_h2_usable first), whose partial tiles carry the square of the input scale:
+// hand the same slots to gram_finish_launch.
+bool gram_h2_usable(const float *feat, int C, int HW);
+int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials,
+                         const unsigned *f_amax = nullptr);
 // gram_out (lower-tri, upper zero) = sum_s partials * 1/(C*HW).  If target != null also writes
 // dsym = sym(tril(gram - target)) and sumsq[0] = sum over the lower triangle of (gram-target)^2.
 // `pieces` (optional, with target): dsym split into three bf16 matrices [3][C][C] for symm_bf3_launch
 // (C a multiple of 64).  sumsq == null: the per-block sums of squares are left behind the Gram
 // partials (gram_finish_blocks(plan) floats at partials + plan.partial_floats) for the caller to add.
 int gram_finish_blocks(const GramPlan &plan);
+// With a target, gram_finish_blocks(plan) words of float bits follow the block sums: max |dsym| per
+// block (symm_h2_launch's d_amax).  f_amax: see gram_partials_launch.
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
-                       const float *target, float *dsym, float *sumsq, unsigned short *pieces = nullptr);
+                       const float *target, float *dsym, float *sumsq, unsigned short *pieces = nullptr,
+                       const unsigned *f_amax = nullptr);
 
 // S = dsym F (+ per-workgroup partial sums of |S|) on the bf16 matrix cores, three-piece split
 // (symm.hip).  `pieces` is scratch for the split dsym: symm_pieces_elems(C) 16-bit words.
@@ -329,6 +337,12 @@ size_t symm_pieces_elems(int C);
 int symm_num_workgroups(int C, int HW);
 bool symm_bf3_usable(const float *feat, const float *out, int C, int HW);
 // pieces_ready: gram_finish_launch already wrote them (else they are made from dsym here)
+// The same product with two fp16 pieces per operand, three products (f16x2.h): dsym is read as it
+// is; d_amax = n_damax words of float bits whose largest is max |dsym|, f_amax = kAmaxSlots words
+// bounding |feat|.
+bool symm_h2_usable(const float *feat, const float *out, int C, int HW);
+int symm_h2_launch(hipStream_t s, const float *feat, const float *dsym, const unsigned *d_amax, int n_damax,
+                   const unsigned *f_amax, float *out, float *partials, int C, int HW);
 int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigned short *pieces,
                     bool pieces_ready, float *out, float *partials, int C, int HW);
 

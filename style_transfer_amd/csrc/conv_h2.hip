@@ -53,6 +53,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "f16x2.h"
 
 #ifndef STX_H2_SKIP
 #define STX_H2_SKIP 0   // timing experiments (tools/ubench/h2conv_bench.hip): 1 no staging, 2 no filter
@@ -108,16 +109,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// power of two s (as an exponent) with amax * 2^s in [2^13, 2^14); amax given as float bits
-__host__ __device__ inline int h2_scale_exp(unsigned amax_bits) {
-    const int e = (int)((amax_bits >> 23) & 0xffu);      // biased exponent of the maximum
-    int s = 13 - (e - 127);
-    return s < -126 ? -126 : s > 127 ? 127 : s;          // (zero blobs: any scale does)
-}
-__device__ __forceinline__ float pow2f(int e) {          // 2^e, e clamped to the normal range
-    const int b = e + 127;
-    return __builtin_bit_cast(float, (unsigned)(b < 1 ? 1 : b > 254 ? 254 : b) << 23);
-}
+// (h2_scale_exp, pow2f: f16x2.h)
 
 }  // namespace
 

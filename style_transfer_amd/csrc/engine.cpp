@@ -873,8 +873,11 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
 // Style terms of one tapped blob, the launches of style_transfer.py:584-593 in order: Gram of
 // `feat` -> D = G - target (fp32 + bf16 pieces) -> S = sym(D) feat into `sgrad`;
 // sc[0] = sum of squares of tril(D), sc[1] = sum |S| (one small launch for both).
+// f_amax (or null): the kAmaxSlots words bounding |feat| that its producer left -- the fp16 two-piece
+// Gram and SYMM kernels (f16x2.h) scale by them; without them a pass over `feat` comes first.
 int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
-                       const float *target, float *sgrad, float *sc, const std::string &name) {
+                       const float *target, float *sgrad, float *sc, const std::string &name,
+                       const unsigned *f_amax = nullptr) {
     const int HW = h * w;
     // the first layer's kernel may have left this blob's Gram partials already (conv_first.hip)
     const bool fused = e->first_gram_valid && e->first_gram_blob >= 0 &&
@@ -888,19 +891,36 @@ int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int
     }
     const int fin_blocks = gram_finish_blocks(plan);
     float *const partials = fused ? e->first_gram.f() : nullptr;
-    if (!fused) STX_TRY(e->gram_partials.ensure((plan.partial_floats + fin_blocks) * sizeof(float)));
+    // (behind the partial tiles: gram_finish's per-block sums of squares and maxima)
+    if (!fused) STX_TRY(e->gram_partials.ensure((plan.partial_floats + 2 * fin_blocks) * sizeof(float)));
     STX_TRY(e->dsym.ensure((size_t)C * C * sizeof(float)));
-    const bool bf3 = symm_bf3_usable(feat, sgrad, C, HW);
+    const bool gram_h2 = !fused && gram_h2_usable(feat, C, HW);
+    const bool symm_h2 = symm_h2_usable(feat, sgrad, C, HW);
+    const bool bf3 = !symm_h2 && symm_bf3_usable(feat, sgrad, C, HW);
+    if ((gram_h2 || symm_h2) && !f_amax) {
+        STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
+        unsigned *scratch = e->amax_slots((int)e->blobs.size(), true);
+        ProfScope scope(e, "absmax " + name, 0.0, stream);
+        STX_TRY(absmax_launch(stream, feat, (size_t)C * HW, scratch));
+        f_amax = scratch;
+    }
     if (bf3) STX_TRY(e->dsym_pieces.ensure(symm_pieces_elems(C) * sizeof(unsigned short)));
     unsigned short *pieces = bf3 && C % 64 == 0 ? static_cast<unsigned short *>(e->dsym_pieces.ptr) : nullptr;
     {
         ProfScope scope(e, "gram " + name, 2.0 * C * C * (double)HW, stream);
-        if (!fused) STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f()));
+        if (!fused) STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f(), gram_h2 ? f_amax : nullptr));
         STX_TRY(gram_finish_launch(stream, fused ? partials : e->gram_partials.f(), plan, nullptr, target,
-                                   e->dsym.f(), nullptr, pieces));
+                                   e->dsym.f(), nullptr, pieces, gram_h2 ? f_amax : nullptr));
     }
     ProfScope scope(e, "symm " + name, 2.0 * C * C * (double)HW, stream);
     const float *block_sumsq = (fused ? partials : e->gram_partials.f()) + plan.partial_floats;
+    if (symm_h2) {
+        const int n_wg = symm_num_workgroups(C, HW);
+        STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+        STX_TRY(symm_h2_launch(stream, feat, e->dsym.f(), reinterpret_cast<const unsigned *>(block_sumsq + fin_blocks),
+                               fin_blocks, f_amax, sgrad, e->symm_partials.f(), C, HW));
+        return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
+    }
     if (bf3) {
         const int n_wg = symm_num_workgroups(C, HW);
         STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
@@ -1690,8 +1710,10 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 size_t si;
                 STX_TRY(alloc_scalars(e, 2, &si));
                 float *sc = e->A().scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
+                // (the maximum the blob's producer left, if it left one: the fp16-split kernels' scale)
+                const unsigned *f_amax = b.amax_data >= 0 ? e->amax_slots(b.amax_data, false) : nullptr;
                 STX_TRY(launch_style_terms(e, e->stream, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
-                                           b.name));
+                                           b.name, f_amax));
                 (void)HW;
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
                 terms[k].push_back(Term{true, sgrad, sc + 1,
@@ -1922,9 +1944,16 @@ int stx_gram_matrix(stx_engine *e, const float *feat, int feat_mem, int channels
     const GramPlan plan = gram_plan(channels, hw);
     STX_TRY(e->gram_partials.ensure(plan.partial_floats * sizeof(float)));
     STX_TRY(e->gram.ensure((size_t)channels * channels * sizeof(float)));
-    STX_TRY(gram_partials_launch(e->stream, src, plan, e->gram_partials.f()));
+    const unsigned *f_amax = nullptr;
+    if (gram_h2_usable(src, channels, hw)) {       // the fp16 two-piece kernel: scaled by the array's maximum
+        STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
+        unsigned *scratch = e->amax_slots((int)e->blobs.size(), true);
+        STX_TRY(absmax_launch(e->stream, src, (size_t)channels * hw, scratch));
+        f_amax = scratch;
+    }
+    STX_TRY(gram_partials_launch(e->stream, src, plan, e->gram_partials.f(), f_amax));
     STX_TRY(gram_finish_launch(e->stream, e->gram_partials.f(), plan, e->gram.f(), nullptr, nullptr,
-                               nullptr));
+                               nullptr, nullptr, f_amax));
     STX_TRY(copy_out(e, gram_out, gram_mem, e->gram.ptr, (size_t)channels * channels * sizeof(float)));
     if (feat_mem == STX_HOST || gram_mem == STX_HOST) STX_HIP(hipStreamSynchronize(e->stream));
     return STX_OK;

@@ -22,6 +22,7 @@
 
 #include "bf16x3.h"
 #include "common.h"
+#include "f16x2.h"
 
 namespace stx {
 
@@ -494,17 +495,183 @@ __global__ __launch_bounds__(256, 2) void gram_partial_bf3_kernel(const float *_
     }
 }
 
-// STX_GRAM=fp32 (read at every call) keeps the fp32-MFMA kernels, for A/B measurements and tests.
+// ------------------------------------------------------------------------------------------------
+// The same kernel on the fp16 matrix cores with two-piece operands (f16x2.h; round 5): three products
+// per step instead of six, two vector instructions per element for the split instead of 5.5.  The
+// scale is the power of two that puts the blob's maximum (f_amax: the kAmaxSlots words its producer
+// left, or absmax_launch) into [2^13, 2^14).
+__global__ __launch_bounds__(256, 2) void gram_partial_h2_kernel(const float *__restrict__ F, int C,
+                                                                  int HW, int tiles, int slice,
+                                                                 unsigned f_bytes,
+                                                                 const unsigned *__restrict__ f_amax,
+                                                                 float *__restrict__ partials) {
+    // two stages of [A tile | B tile] in LDS: stage s + 1 is written while stage s is multiplied,
+    // one barrier per stage, and the loads of stage s + 2 are in flight for a whole stage
+    constexpr int kStageFloats = 2 * kGT * kGLdW;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // XCD-aware order, as gram_partial_wide_kernel
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int tile = L % tiles, split = L / tiles;
+    int ti, tj;
+    tile_coords(tile, ti, tj);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    const bool diag = ti == tj;
+    const int p_begin = split * slice;
+    const int p_end = min(HW, p_begin + slice);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging exactly as gram_partial_wide_kernel: fp32 tiles [64 channels][64 pixels + 4] in LDS,
+    // coalesced 16-byte buffer loads (a wave covers 4 channel rows x 256 bytes)
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, f_bytes, 0x00020000);
+    unsigned aoff[4], boff[4];
+    int ldst[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;                 // float4 index in the 64 x 16 tile
+        const int ch = e >> 4, px = (e & 15) * 4;
+        const int ca = ti * kGT + ch, cb = tj * kGT + ch;
+        aoff[n] = ca < C ? (unsigned)(ca * HW + px) * 4u : kOob;
+        boff[n] = cb < C && !diag ? (unsigned)(cb * HW + px) * 4u : kOob;
+        ldst[n] = ch * kGLdW + px;
+    }
+    u32x4g ra[4], rb[4];
+    auto load = [&](int p0) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(p0 * 4);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ra[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, aoff[n], so, 0);
+        if (!diag) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) rb[n] = __builtin_amdgcn_raw_buffer_load_b128(rf, boff[n], so, 0);
+        }
+    };
+    auto store = [&](int p0, int buf) {
+        float *At = lds + buf * kStageFloats, *Bt = At + kGT * kGLdW;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int rem = p_end - (p0 + ((tid + 256 * n) & 15) * 4);
+            u32x4g va = ra[n], vb = rb[n];
+            if (rem < 4) {
+                va.x = rem > 0 ? va.x : 0u, va.y = rem > 1 ? va.y : 0u, va.z = rem > 2 ? va.z : 0u, va.w = 0u;
+                vb.x = rem > 0 ? vb.x : 0u, vb.y = rem > 1 ? vb.y : 0u, vb.z = rem > 2 ? vb.z : 0u, vb.w = 0u;
+            }
+            *reinterpret_cast<u32x4g *>(At + ldst[n]) = va;
+            if (!diag) *reinterpret_cast<u32x4g *>(Bt + ldst[n]) = vb;
+        }
+    };
+
+    // Fragments as in gram_partial_bf3_kernel, split into the two fp16 pieces in registers.
+    const int a_off = l31 * kGLdW + wave * 16 + half * 8;
+    const int b_off = (diag ? 0 : kGT * kGLdW) + a_off;
+    // (both operands carry the scale: the partial tiles are 2^(2 es) times the products, undone by
+    // gram_finish_kernel -- exact)
+    const float sv = pow2f(h2_scale_exp(amax_of_slots(f_amax, kAmaxSlots)));
+    auto fragment = [&](const float *q, f16x8h &hi, f16x8h &lo) {
+        const f32x4g v0 = *reinterpret_cast<const f32x4g *>(q);
+        const f32x4g v1 = *reinterpret_cast<const f32x4g *>(q + 4);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        split2_f16(x, sv, hi, lo);
+    };
+
+    if (p_begin < p_end) {
+        load(p_begin);
+        store(p_begin, 0);
+        if (p_begin + kGP < p_end) load(p_begin + kGP);
+        __syncthreads();
+        int buf = 0;
+        for (int p0 = p_begin; p0 < p_end; p0 += kGP, buf ^= 1) {
+            const float *base = lds + buf * kStageFloats;
+            f16x8h ah[2], al[2], bh[2], bl[2];
+            fragment(base + a_off, ah[0], al[0]);
+            fragment(base + a_off + 32 * kGLdW, ah[1], al[1]);
+            if (!diag) {
+                fragment(base + b_off, bh[0], bl[0]);
+                fragment(base + b_off + 32 * kGLdW, bh[1], bl[1]);
+            }
+            // the other buffer was last read in the previous stage, which every wave has left
+            if (p0 + kGP < p_end) store(p0 + kGP, buf ^ 1);
+            if (p0 + 2 * kGP < p_end) load(p0 + 2 * kGP);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (diag && j > i) continue;      // upper block of a diagonal tile
+                    acc[i][j] = mfma_split3(ah[i], al[i], diag ? ah[j] : bh[j], diag ? al[j] : bl[j], acc[i][j]);
+                }
+            __syncthreads();
+        }
+    }
+    // the four waves' partial tiles side by side in LDS (4 x 16 KB: the two stages are free now),
+    // one barrier, then every thread adds its 16 elements in wave order -- ((w0 + w1) + w2) + w3,
+    // the order of the fp32 kernel's four sequential rounds, bit for bit -- and writes them
+    float *red = lds + wave * (kGT * kGT);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[row * kGT + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+    static_assert(4 * kGT * kGT <= 2 * kStageFloats, "the four partial tiles must fit the stage buffers");
+    float *out = partials + ((size_t)split * tiles + tile) * (kGT * kGT);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int e = tid + 256 * n;
+        const float4 w0 = reinterpret_cast<const float4 *>(lds)[e];
+        const float4 w1 = reinterpret_cast<const float4 *>(lds + kGT * kGT)[e];
+        const float4 w2 = reinterpret_cast<const float4 *>(lds + 2 * kGT * kGT)[e];
+        const float4 w3 = reinterpret_cast<const float4 *>(lds + 3 * kGT * kGT)[e];
+        float4 v;
+        v.x = ((w0.x + w1.x) + w2.x) + w3.x;
+        v.y = ((w0.y + w1.y) + w2.y) + w3.y;
+        v.z = ((w0.z + w1.z) + w2.z) + w3.z;
+        v.w = ((w0.w + w1.w) + w2.w) + w3.w;
+        reinterpret_cast<float4 *>(out)[e] = v;
+    }
+}
+
+// STX_GRAM=fp32 (read at every call) keeps the fp32-MFMA kernels, =bf3 the three-piece bf16 kernel,
+// for A/B measurements and tests.
 static bool gram_use_bf3() {
     const char *env = getenv("STX_GRAM");
     return !(env && !strcmp(env, "fp32"));
 }
 
-int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials) {
+bool gram_h2_usable(const float *feat, int C, int HW) {
+    const char *env = getenv("STX_GRAM");
+    if (env && (!strcmp(env, "fp32") || !strcmp(env, "bf3"))) return false;
+    return (reinterpret_cast<uintptr_t>(feat) & 3) == 0 && 4.0 * C * (double)HW < 2147483648.0;
+}
+
+int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan, float *partials,
+                         const unsigned *f_amax) {
     int slice = ceil_div(plan.HW, plan.splits);
     slice = ceil_div(slice, kGP) * kGP;
     const bool aligned = (reinterpret_cast<uintptr_t>(feat) & 15) == 0;
     const double bytes = 4.0 * plan.C * (double)plan.HW;
+    if (f_amax) {        // the caller has asked gram_h2_usable
+        gram_partial_h2_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
+            feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, f_amax, partials);
+        STX_CHECK_LAUNCH();
+        return STX_OK;
+    }
     if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && gram_use_bf3()) {
         gram_partial_bf3_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
             feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, partials);
@@ -534,15 +701,24 @@ int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan,
 // 64 consecutive (i, j) elements per workgroup, each summed by four "split lanes" that walk the
 // slices with a stride of four (independent partial sums -> memory-level parallelism); the four
 // lanes are then added in a fixed order, so the result does not depend on scheduling.
+// f_amax (or null): the partial tiles came from gram_partial_h2_kernel, i.e. they are 2^(2 es) times
+// the products, es the scale exponent of those slots -- undone here (exact).  block_amax (with
+// target): max |G - Gs| of the block as float bits, for symm_h2_kernel's scale (plain stores: no
+// memset, no atomics; blocks of the upper triangle leave 0).
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restrict__ partials, int C,
                                                           int tiles, int splits, float scale,
                                                           float *__restrict__ gram,
                                                           const float *__restrict__ target,
                                                           float *__restrict__ dsym,
                                                           float *__restrict__ block_sumsq,
-                                                          unsigned short *__restrict__ pieces) {
+                                                          unsigned short *__restrict__ pieces,
+                                                          const unsigned *__restrict__ f_amax,
+                                                          unsigned *__restrict__ block_amax) {
     __shared__ float lane_sum[4][64];
     __shared__ float red[64];
+    __shared__ float redm[64];
+    float unscale = 1.f;
+    if (f_amax) unscale = pow2f(-h2_scale_exp(amax_of_slots(f_amax, kAmaxSlots)));
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + el;
     const bool valid = idx < C * C;
@@ -575,11 +751,12 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
     }
     lane_sum[sl][el] = sum;
     __syncthreads();
-    float sq = 0.f;
+    float sq = 0.f, dmax = 0.f;
     if (sl == 0 && valid) {
         if (lower) {
-            const float g = ((lane_sum[0][el] + lane_sum[1][el]) + (lane_sum[2][el] + lane_sum[3][el])) *
-                            scale;
+            // (the two powers of two first: exact, and neither can leave the normal range alone)
+            const float g = ((((lane_sum[0][el] + lane_sum[1][el]) + (lane_sum[2][el] + lane_sum[3][el])) *
+                              unscale) * unscale) * scale;
             if (gram) gram[idx] = g;
             if (target) {
                 const float d = g - target[i * C + j];
@@ -596,18 +773,24 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float *__restric
                     }
                 }
                 sq = d * d;
+                dmax = fabsf(d);
             }
         } else if (gram) {
             gram[idx] = 0.f;
         }
     }
     if (block_sumsq) {
-        if (sl == 0) red[el] = sq;
+        if (sl == 0) red[el] = sq, redm[el] = dmax;
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = 0.f;
             for (int k = 0; k < 64; ++k) t += red[k];
             block_sumsq[blockIdx.x] = t;
+        }
+        if (threadIdx.x == 64 && block_amax) {
+            float m = 0.f;
+            for (int k = 0; k < 64; ++k) m = fmaxf(m, redm[k]);
+            block_amax[blockIdx.x] = __builtin_bit_cast(unsigned, m);
         }
     }
 }
@@ -662,14 +845,17 @@ int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, co
 int gram_finish_blocks(const GramPlan &plan) { return ceil_div(plan.C * plan.C, 64); }
 
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
-                       const float *target, float *dsym, float *sumsq, unsigned short *pieces) {
+                       const float *target, float *dsym, float *sumsq, unsigned short *pieces,
+                       const unsigned *f_amax) {
     const int blocks = gram_finish_blocks(plan);
-    // block partial sums live behind the Gram partials (the caller sizes the buffer for both)
+    // block partial sums, and behind them the block maxima, live behind the Gram partials (the caller
+    // sizes the buffer for all three)
     float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
+    unsigned *block_amax = target ? reinterpret_cast<unsigned *>(block_sumsq + blocks) : nullptr;
     const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
     gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits * plan.parts, scale,
                                               gram_out, target, dsym, block_sumsq,
-                                              target ? pieces : nullptr);
+                                              target ? pieces : nullptr, f_amax, block_amax);
     STX_CHECK_LAUNCH();
     // sumsq == null: the caller adds the block partials (behind the Gram partials) up itself
     if (target && sumsq) STX_TRY(sum_partials_launch(s, block_sumsq, blocks, sumsq));

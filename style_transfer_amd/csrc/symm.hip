@@ -17,6 +17,14 @@
 //   * a wave owns 64 channels x 64 pixels of S (four 32x32 blocks), a workgroup 64 x 256; the
 //     channel tiles of one pixel tile run on one XCD (they read the same columns of F).
 // Sums of |S| are added per lane, per wave, per workgroup in a fixed order (deterministic).
+//
+// Round 5: symm_h2_kernel, the same work split on the fp16 matrix cores with TWO fp16 pieces per
+// operand and three products per step (f16x2.h): half the matrix time of the six-product form, two
+// vector instructions per element for the split instead of 5.5, and D staged from the fp32 matrix
+// itself (8 KB per chunk instead of 12 KB of ready pieces; the split rides in the MFMAs' shadow), so
+// gram_finish_kernel writes no piece matrices.  The scales are powers of two taken from the
+// operands' own maxima: F's from the slots its producer left (the engine's table), D's from the
+// per-block maxima gram_finish_kernel leaves beside its sums of squares.
 
 #include <algorithm>
 #include <cstdlib>
@@ -24,6 +32,7 @@
 
 #include "bf16x3.h"
 #include "common.h"
+#include "f16x2.h"
 
 #ifndef STX_SYMM_SKIP
 #define STX_SYMM_SKIP 0   // timing experiments (tools/ubench/symm_bench.hip): 1 no MFMAs, 2 no split, 4 no F
@@ -238,6 +247,197 @@ __global__ __launch_bounds__(256, 2) void symm_bf3_kernel(const float *__restric
     if (tid == 0) partials[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fp16 two-piece form (f16x2.h).  D = [C][C] fp32 (symmetric, dense); d_amax = n_damax words
+// of float bits whose largest is max |D| (gram_finish_kernel's block maxima); f_amax = kAmaxSlots
+// words of float bits bounding |F|.
+constexpr int kHChunkBytes = 2 * kPieceBytes;
+constexpr int kHDLoads = kSM * kSK / 4 / 256;    // 16-byte loads of fp32 D per thread and chunk
+
+template <bool BIG>
+__global__ __launch_bounds__(256, 2) void symm_h2_kernel(const float *__restrict__ F,
+                                                         const float *__restrict__ D,
+                                                         const unsigned *__restrict__ d_amax, int n_damax,
+                                                         const unsigned *__restrict__ f_amax,
+                                                         float *__restrict__ S,
+                                                         float *__restrict__ partials, int C, int Cp,
+                                                         int HW, unsigned f_bytes, int m_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHChunkBytes];
+    __shared__ float wave_sum[4];
+    __shared__ unsigned wave_max[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, g = lane >> 5;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mt = __builtin_amdgcn_readfirstlane(L % m_tiles), pt = __builtin_amdgcn_readfirstlane(L / m_tiles);
+    const int m0 = mt * kSM;
+    const int px0 = pt * kSN + wave * 64;
+
+    constexpr unsigned kOob = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rf =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F), 0, BIG ? 0 : f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(S, 0, BIG ? 0 : f_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(D), 0, (unsigned)(C * C) * 4u, 0x00020000);
+    unsigned voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int px = px0 + j * 32 + l31;
+        voff[j] = px < HW ? (unsigned)((g * 8) * HW + px) * 4u : kOob;
+    }
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const int n_steps = Cp / 16, n_chunks = Cp / kSK;
+
+    // ---- D chunk staging: 64 rows x kSK columns of fp32 = kHDLoads 16-byte loads per thread; rows
+    // and columns past C read as zero (range check / explicit column test: C is a multiple of 4)
+    unsigned dvoff[kHDLoads], ddst[kHDLoads];
+    int dcol[kHDLoads];
+#pragma unroll
+    for (int n = 0; n < kHDLoads; ++n) {
+        const int e = tid + 256 * n;                 // (row, 4-column segment)
+        const int row = e / (kSK / 4), seg = e - row * (kSK / 4);
+        dcol[n] = seg * 4;
+        dvoff[n] = m0 + row < C ? (unsigned)((m0 + row) * C + seg * 4) * 4u : kOob;
+        ddst[n] = (unsigned)(row * kRowBytes + seg * 8);
+    }
+    u32x4y dreg[kHDLoads];
+    auto d_load = [&](int chunk) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(chunk * kSK * 4);
+#pragma unroll
+        for (int n = 0; n < kHDLoads; ++n)
+            dreg[n] = __builtin_amdgcn_raw_buffer_load_b128(rd, dcol[n] + chunk * kSK < C ? dvoff[n] : kOob, so, 0);
+    };
+
+    float raw[kRing][2][8];
+    auto f_load = [&](int step, int slot_) {
+        const int k0 = __builtin_amdgcn_readfirstlane(step * 16);
+        const int left = C - k0 < 16 ? C - k0 : 16;
+        const __amdgpu_buffer_rsrc_t rk =
+            BIG ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F) + (size_t)k0 * (size_t)HW, 0,
+                                                    (left > 0 ? left : 0) * HW * 4, 0x00020000)
+                : rf;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                raw[slot_][j][e] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(
+                               rk, voff[j], BIG ? (unsigned)e * HW4 : (unsigned)min(k0 + e, C) * HW4, 0));
+    };
+
+    f32x16h acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // the first loads go out before the scales are known
+    d_load(0);
+#pragma unroll
+    for (int r = 0; r < kRing - 1; ++r)
+        if (r < n_steps) f_load(r, r);
+
+    // ---- scales: F's from its producer's slots, D's from the block maxima (workgroup-wide maximum)
+    const int ef = h2_scale_exp(amax_of_slots(f_amax, kAmaxSlots));
+    unsigned dm = 0;
+    for (int i = tid; i < n_damax; i += 256) dm = max(dm, d_amax[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dm = max(dm, (unsigned)__shfl_xor((int)dm, off, 64));
+    if (lane == 0) wave_max[wave] = dm;
+    __syncthreads();
+    dm = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    const int ed = __builtin_amdgcn_readfirstlane(h2_scale_exp(dm));
+    const float sf = pow2f(ef), sd = pow2f(ed);
+
+    auto d_store = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < kHDLoads; ++n) {
+            unsigned h[2], l[2];
+            // (through scalars: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this compiler)
+            const unsigned d0 = dreg[n].x, d1 = dreg[n].y, d2 = dreg[n].z, d3 = dreg[n].w;
+            split2_f16_quad(__builtin_bit_cast(float, d0), __builtin_bit_cast(float, d1),
+                            __builtin_bit_cast(float, d2), __builtin_bit_cast(float, d3), sd, h, l);
+            typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+            unsigned char *q = lds + buf * kHChunkBytes + ddst[n];
+            *reinterpret_cast<u32x2s *>(q) = (u32x2s){h[0], h[1]};
+            *reinterpret_cast<u32x2s *>(q + kPieceBytes) = (u32x2s){l[0], l[1]};
+        }
+    };
+    d_store(0);
+    if (n_chunks > 1) d_load(1);
+    __syncthreads();
+
+    const unsigned a_off = (unsigned)(l31 * kRowBytes + g * 16);
+    auto do_step = [&](int slot_, int buf, int s_in_chunk) {
+        f16x8h bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) split2_f16(raw[slot_][j], sf, bh[j], bl[j]);
+        const unsigned char *base = lds + buf * kHChunkBytes + a_off + s_in_chunk * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8h *>(base + i * 32 * kRowBytes);
+            al[i] = *reinterpret_cast<const f16x8h *>(base + kPieceBytes + i * 32 * kRowBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+    };
+
+    int step = 0;
+    auto advance = [&](int slot_) {
+        const int chunk = step / kSPC, s_in = step % kSPC, buf = chunk & 1;
+        if (step + kRing - 1 < n_steps) f_load(step + kRing - 1, (slot_ + kRing - 1) % kRing);
+        do_step(slot_, buf, s_in);
+        if (s_in == kSPC - 1) {
+            if (chunk + 1 < n_chunks) d_store(buf ^ 1);
+            if (chunk + 2 < n_chunks) d_load(chunk + 2);
+            __syncthreads();
+        }
+        ++step;
+    };
+    while (step < n_steps) {
+#pragma unroll
+        for (int r = 0; r < kRing; ++r)
+            if (step < n_steps) advance(r);
+    }
+
+    // ---- S tile out (both scales undone: exact), |S| summed as in symm_bf3_kernel
+    const float ud = pow2f(-ed), uf = pow2f(-ef);
+    float asum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int row0 = min(__builtin_amdgcn_readfirstlane(m0 + i * 32 + (r & 3) + 8 * (r >> 2)), C);
+            const unsigned so = BIG ? 0u : (unsigned)row0 * HW4;
+            const int rows_left = C - row0 < 5 ? C - row0 : 5;
+            const __amdgpu_buffer_rsrc_t rrow =
+                BIG ? __builtin_amdgcn_make_buffer_rsrc(S + (size_t)row0 * (size_t)HW, 0,
+                                                        (rows_left > 0 ? rows_left : 0) * HW * 4, 0x00020000)
+                    : rs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = px0 + j * 32 + l31;
+                const bool ok = row < C && px < HW;
+                const float v = (acc[i][j][r] * ud) * uf;
+                asum += ok ? fabsf(v) : 0.f;
+                const unsigned vo = ok ? (unsigned)((4 * g) * HW + px) * 4u : kOob;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rrow, vo, so, 0);
+            }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    if (lane == 0) wave_sum[wave] = asum;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
+}
+
 // dsym [C][C] fp32 -> pieces [3][Cp][Cp] bf16 (zero padded to a multiple of 64)
 __global__ void symm_split_kernel(const float *__restrict__ dsym, int C, int Cp,
                                   unsigned short *__restrict__ pieces) {
@@ -277,6 +477,29 @@ int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigne
     else
         symm_bf3_kernel<false><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, pieces, out, partials, C, Cp,
                                                                         HW, (unsigned)bytes, m_tiles);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+// STX_SYMM=bf3 keeps the three-piece bf16 kernel, =fp32 the fp32-MFMA path (read at every call)
+bool symm_h2_usable(const float *feat, const float *out, int C, int HW) {
+    const char *env = getenv("STX_SYMM");
+    if (env && (!strcmp(env, "fp32") || !strcmp(env, "bf3"))) return false;
+    return C % 4 == 0 && symm_bf3_usable(feat, out, C, HW);
+}
+
+int symm_h2_launch(hipStream_t s, const float *feat, const float *dsym, const unsigned *d_amax, int n_damax,
+                   const unsigned *f_amax, float *out, float *partials, int C, int HW) {
+    const int Cp = ceil_div(C, kSM) * kSM;
+    const int m_tiles = Cp / kSM;
+    const double bytes = 4.0 * C * (double)HW;
+    const char *force_big = getenv("STX_WINO_BIG");
+    if (bytes >= 2147483648.0 || (force_big && atoi(force_big) == 1))
+        symm_h2_kernel<true><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, dsym, d_amax, n_damax, f_amax, out,
+                                                                      partials, C, Cp, HW, 0u, m_tiles);
+    else
+        symm_h2_kernel<false><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, dsym, d_amax, n_damax, f_amax, out,
+                                                                       partials, C, Cp, HW, (unsigned)bytes, m_tiles);
     STX_CHECK_LAUNCH();
     return STX_OK;
 }
