@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -327,9 +329,10 @@ int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan,
 int gram_finish_blocks(const GramPlan &plan);
 // With a target, gram_finish_blocks(plan) words of float bits follow the block sums: max |dsym| per
 // block (symm_h2_launch's d_amax).  f_amax: see gram_partials_launch.
+// block_out (or null: behind the Gram partials): where the 2 x gram_finish_blocks(plan) block words go.
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
                        const float *target, float *dsym, float *sumsq, unsigned short *pieces = nullptr,
-                       const unsigned *f_amax = nullptr);
+                       const unsigned *f_amax = nullptr, float *block_out = nullptr);
 
 // S = dsym F (+ per-workgroup partial sums of |S|) on the bf16 matrix cores, three-piece split
 // (symm.hip).  `pieces` is scratch for the split dsym: symm_pieces_elems(C) 16-bit words.
@@ -363,8 +366,18 @@ __device__ __forceinline__ size_t content_index(const ContentWindow &w, int c, i
 }
 #endif
 
+// A final sum a caller may postpone: dst[0] = the n floats at src, added in the fixed order of
+// sum_partials_kernel.  The tile path collects the jobs of all its loss terms and runs them as ONE
+// launch behind the forward pass (sum_jobs_launch) -- a dispatch costs ~5 us however little it does.
+struct SumJob {
+    const float *src;
+    int n;
+    float *dst;
+};
+int sum_jobs_launch(hipStream_t s, const SumJob *jobs, int n_jobs);
+// defer (or null: the two sums are launched here): receives the two jobs instead
 int content_sums_launch(hipStream_t s, const float *feat, const float *content,
-                        const ContentWindow &win, float *sums /*[2]*/);
+                        const ContentWindow &win, float *sums /*[2]*/, std::vector<SumJob> *defer = nullptr);
 // diff (=|+=) coef / (abs_sum/n + EPS) * term, term = S (style) or F - Fc (content).
 // y_amax (optional, zeroed by the caller): max |value written| for a conv_h2 launch that reads diff next
 int inject_style_launch(hipStream_t s, float *diff, const float *sgrad, size_t n,

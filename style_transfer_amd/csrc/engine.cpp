@@ -169,6 +169,7 @@ struct stx_engine {
     int first_gram_blob = -1, first_gram_parts = 0;
     bool first_gram_valid = false;
     DevBuf gram_partials, gram, dsym, dsym_pieces, symm_partials, upload;
+    DevBuf term_scratch;               // per style term of a tile call: block sums / maxima + SYMM partials (sum jobs)
     // Loss scalars of the calls queued so far: device floats (tile terms) and doubles (image-op
     // reductions), each with a pinned host mirror, and the losses that will be published from
     // them.  TWO arenas: stx_fence closes the current one behind an event and opens the other, so
@@ -875,9 +876,17 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
 // sc[0] = sum of squares of tril(D), sc[1] = sum |S| (one small launch for both).
 // f_amax (or null): the kAmaxSlots words bounding |feat| that its producer left -- the fp16 two-piece
 // Gram and SYMM kernels (f16x2.h) scale by them; without them a pass over `feat` comes first.
+// term_scratch + defer (or null: sc[0], sc[1] are final when this returns): 2 x gram_finish's blocks +
+// the SYMM kernel's workgroups floats that outlive the call (style_term_scratch_floats), and the list
+// that receives the two final sums for ONE launch behind the forward pass (sum_jobs_launch).
+size_t style_term_scratch_floats(int C, int HW) {
+    return 2 * (size_t)ceil_div(C * C, 64) + (size_t)symm_num_workgroups(C, HW) + 64;
+}
+
 int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int C, int h, int w,
                        const float *target, float *sgrad, float *sc, const std::string &name,
-                       const unsigned *f_amax = nullptr) {
+                       const unsigned *f_amax = nullptr, float *term_scratch = nullptr,
+                       std::vector<SumJob> *defer = nullptr) {
     const int HW = h * w;
     // the first layer's kernel may have left this blob's Gram partials already (conv_first.hip)
     const bool fused = e->first_gram_valid && e->first_gram_blob >= 0 &&
@@ -910,23 +919,32 @@ int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int
         ProfScope scope(e, "gram " + name, 2.0 * C * C * (double)HW, stream);
         if (!fused) STX_TRY(gram_partials_launch(stream, feat, plan, e->gram_partials.f(), gram_h2 ? f_amax : nullptr));
         STX_TRY(gram_finish_launch(stream, fused ? partials : e->gram_partials.f(), plan, nullptr, target,
-                                   e->dsym.f(), nullptr, pieces, gram_h2 ? f_amax : nullptr));
+                                   e->dsym.f(), nullptr, pieces, gram_h2 ? f_amax : nullptr,
+                                   defer ? term_scratch : nullptr));
     }
     ProfScope scope(e, "symm " + name, 2.0 * C * C * (double)HW, stream);
-    const float *block_sumsq = (fused ? partials : e->gram_partials.f()) + plan.partial_floats;
-    if (symm_h2) {
+    const float *block_sumsq = defer ? term_scratch : (fused ? partials : e->gram_partials.f()) + plan.partial_floats;
+    // the two final sums: now, or as two jobs of the caller's one launch
+    auto finish = [&](float *symm_partials, int n_wg) -> int {
+        if (!defer) return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, symm_partials, n_wg, sc + 1);
+        defer->push_back(SumJob{block_sumsq, fin_blocks, sc});
+        defer->push_back(SumJob{symm_partials, n_wg, sc + 1});
+        return STX_OK;
+    };
+    if (symm_h2 || bf3) {
         const int n_wg = symm_num_workgroups(C, HW);
-        STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
-        STX_TRY(symm_h2_launch(stream, feat, e->dsym.f(), reinterpret_cast<const unsigned *>(block_sumsq + fin_blocks),
-                               fin_blocks, f_amax, sgrad, e->symm_partials.f(), C, HW));
-        return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
-    }
-    if (bf3) {
-        const int n_wg = symm_num_workgroups(C, HW);
-        STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
-        STX_TRY(symm_bf3_launch(stream, feat, e->dsym.f(), static_cast<unsigned short *>(e->dsym_pieces.ptr),
-                                pieces != nullptr, sgrad, e->symm_partials.f(), C, HW));
-        return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
+        float *symm_partials = defer ? term_scratch + 2 * fin_blocks : nullptr;
+        if (!defer) {
+            STX_TRY(e->symm_partials.ensure((size_t)n_wg * sizeof(float)));
+            symm_partials = e->symm_partials.f();
+        }
+        if (symm_h2)
+            STX_TRY(symm_h2_launch(stream, feat, e->dsym.f(), reinterpret_cast<const unsigned *>(block_sumsq + fin_blocks),
+                                   fin_blocks, f_amax, sgrad, symm_partials, C, HW));
+        else
+            STX_TRY(symm_bf3_launch(stream, feat, e->dsym.f(), static_cast<unsigned short *>(e->dsym_pieces.ptr),
+                                    pieces != nullptr, sgrad, symm_partials, C, HW));
+        return finish(symm_partials, n_wg);
     }
     const ConvConfig cfg = conv_pick_config(1, C, C, h, w);
     const int n_wg = conv_num_workgroups(cfg, C, h, w);
@@ -943,6 +961,7 @@ int launch_style_terms(stx_engine *e, hipStream_t stream, const float *feat, int
     p.ksize = 1;
     p.epilogue = kEpiSymm;
     STX_TRY(conv_launch(stream, cfg, p, false));
+    // (this path keeps its SYMM partials in the engine's shared buffer: its two sums are launched here)
     return sum_partials2_launch(stream, block_sumsq, fin_blocks, sc, e->symm_partials.f(), n_wg, sc + 1);
 }
 
@@ -1644,6 +1663,22 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     };
     std::vector<std::vector<Term>> terms(order.size());
     while (e->sgrad_tap.size() < order.size()) e->sgrad_tap.emplace_back(new DevBuf);
+    // The final sums of the loss terms (two per style term, two per content term) are collected and run
+    // as ONE launch behind the forward pass (STX_SUMS_LATE=0: each where it arises, as rounds 1-4 did);
+    // what they add up must outlive the term's own launches: one scratch region per style term.
+    const bool sums_late = !(getenv("STX_SUMS_LATE") && !atoi(getenv("STX_SUMS_LATE")));
+    std::vector<SumJob> sum_jobs;
+    size_t scratch_used = 0;
+    if (sums_late) {
+        size_t need = 0;
+        for (const Tap &tp : order) {
+            if (!tp.t->is_style) continue;
+            const Blob &b = e->blobs[tp.blob];
+            for (const StyleTarget &st : e->sh->styles)
+                if (st.blob == tp.blob) need += style_term_scratch_floats(b.channels, b.h * b.w);
+        }
+        STX_TRY(e->term_scratch.ensure(need * sizeof(float)));
+    }
     // Loss terms of tap k (Gram -> G - Gs -> SYMM, content residual sums).  They are queued the
     // moment the tapped blob is complete, in the middle of the forward pass, while the blob is
     // still in the L2 / Infinity Cache the convolution just wrote it through (the shallow blobs
@@ -1678,7 +1713,8 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 float *sums = e->A().scalars.f() + si;
                 {
                     ProfScope scope(e, "content " + b.name, 0.0, e->stream);
-                    STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums));
+                    STX_TRY(content_sums_launch(e->stream, b.data.f(), ct.feat->f(), win, sums,
+                                                sums_late ? &sum_jobs : nullptr));
                 }
                 pl.terms.push_back(LossTerm{si, lw * tp.t->content_weight * 0.5});
                 terms[k].push_back(Term{false, ct.feat->f(), sums,
@@ -1712,8 +1748,13 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
                 float *sc = e->A().scalars.f() + si;   // [0] = sum tril(D)^2, [1] = sum |S|
                 // (the maximum the blob's producer left, if it left one: the fp16-split kernels' scale)
                 const unsigned *f_amax = b.amax_data >= 0 ? e->amax_slots(b.amax_data, false) : nullptr;
+                float *scratch = nullptr;
+                if (sums_late) {
+                    scratch = e->term_scratch.f() + scratch_used;
+                    scratch_used += style_term_scratch_floats(C, HW);
+                }
                 STX_TRY(launch_style_terms(e, e->stream, b.data.f(), C, b.h, b.w, st.gram->f(), sgrad, sc,
-                                           b.name, f_amax));
+                                           b.name, f_amax, scratch, sums_late ? &sum_jobs : nullptr));
                 (void)HW;
                 pl.terms.push_back(LossTerm{si, lw * tp.t->style_weight * 0.5 / e->sh->n_styles});
                 terms[k].push_back(Term{true, sgrad, sc + 1,
@@ -1732,7 +1773,8 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
             float *sums = e->A().scalars.f() + si;
             {
                 ProfScope scope(e, "dream " + b.name, 0.0, e->stream);
-                STX_TRY(content_sums_launch(e->stream, b.data.f(), nullptr, win, sums));
+                STX_TRY(content_sums_launch(e->stream, b.data.f(), nullptr, win, sums,
+                                            sums_late ? &sum_jobs : nullptr));
             }
             pl.terms.push_back(LossTerm{si, -lw * tp.t->dd_weight * 0.5});
             terms[k].push_back(Term{false, nullptr, sums, (float)(-lw * tp.t->dd_weight), win});
@@ -1762,6 +1804,10 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         // (shallowest tap first, the order the interleaved schedule queues them in: the host adds
         // the loss terms up in queueing order, in double precision, and must get the same bits)
         for (size_t k = order.size(); k-- > 0;) STX_TRY(launch_terms(k));
+    }
+    if (!sum_jobs.empty()) {
+        ProfScope scope(e, "sums", 0.0);
+        STX_TRY(sum_jobs_launch(e->stream, sum_jobs.data(), (int)sum_jobs.size()));
     }
 
     // Adds the terms of tap k to its blob's diff with stand-alone kernels (used for the deepest

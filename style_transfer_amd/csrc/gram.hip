@@ -842,15 +842,50 @@ int sum_partials2_launch(hipStream_t s, const float *a, int na, float *out_a, co
     return STX_OK;
 }
 
+// up to kSumJobs postponed sums in one launch: workgroup b adds job b's floats exactly as
+// sum_partials_kernel / sum_partials2_kernel / sum_two_kernel do (thread-strided sums, then a tree
+// over 256 lanes): the same bits, four to five launches fewer per tile evaluation
+constexpr int kSumJobs = 16;
+struct SumJobTable {
+    const float *src[kSumJobs];
+    float *dst[kSumJobs];
+    int n[kSumJobs];
+};
+__global__ void sum_jobs_kernel(SumJobTable t) {
+    __shared__ float red[256];
+    const float *partials = t.src[blockIdx.x];
+    const int n = t.n[blockIdx.x];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) t.dst[blockIdx.x][0] = red[0];
+}
+
+int sum_jobs_launch(hipStream_t s, const SumJob *jobs, int n_jobs) {
+    for (int base = 0; base < n_jobs; base += kSumJobs) {
+        SumJobTable t{};
+        const int m = std::min(kSumJobs, n_jobs - base);
+        for (int i = 0; i < m; ++i) t.src[i] = jobs[base + i].src, t.dst[i] = jobs[base + i].dst, t.n[i] = jobs[base + i].n;
+        sum_jobs_kernel<<<m, 256, 0, s>>>(t);
+        STX_CHECK_LAUNCH();
+    }
+    return STX_OK;
+}
+
 int gram_finish_blocks(const GramPlan &plan) { return ceil_div(plan.C * plan.C, 64); }
 
 int gram_finish_launch(hipStream_t s, const float *partials, const GramPlan &plan, float *gram_out,
                        const float *target, float *dsym, float *sumsq, unsigned short *pieces,
-                       const unsigned *f_amax) {
+                       const unsigned *f_amax, float *block_out) {
     const int blocks = gram_finish_blocks(plan);
     // block partial sums, and behind them the block maxima, live behind the Gram partials (the caller
-    // sizes the buffer for all three)
-    float *block_sumsq = target ? const_cast<float *>(partials) + plan.partial_floats : nullptr;
+    // sizes the buffer for all three) unless the caller names a place
+    float *block_sumsq = !target ? nullptr : block_out ? block_out : const_cast<float *>(partials) + plan.partial_floats;
     unsigned *block_amax = target ? reinterpret_cast<unsigned *>(block_sumsq + blocks) : nullptr;
     const float scale = (float)(1.0 / ((double)plan.C * (double)plan.HW));
     gram_finish_kernel<<<blocks, 256, 0, s>>>(partials, plan.C, plan.tiles, plan.splits * plan.parts, scale,

@@ -101,12 +101,17 @@ __global__ void sum_two_kernel(const float *__restrict__ partials, int n, float 
 // `sums` doubles as scratch: sums[0..1] receive the results, the partials live behind them
 // (the engine reserves 2 + 2*kRedBlocks floats per content tap).
 int content_sums_launch(hipStream_t s, const float *feat, const float *content,
-                        const ContentWindow &win, float *sums) {
+                        const ContentWindow &win, float *sums, std::vector<SumJob> *defer) {
     const size_t total = (size_t)win.C * win.fh * win.fw;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, kRedBlocks);
     float *partials = sums + 2;
     content_sums_kernel<<<blocks, 256, 0, s>>>(feat, content, win, partials);
     STX_CHECK_LAUNCH();
+    if (defer) {        // (sum_jobs_kernel adds in sum_two_kernel's order)
+        defer->push_back(SumJob{partials, blocks, sums});
+        defer->push_back(SumJob{partials + blocks, blocks, sums + 1});
+        return STX_OK;
+    }
     sum_two_kernel<<<1, 256, 0, s>>>(partials, blocks, sums);
     STX_CHECK_LAUNCH();
     return STX_OK;
