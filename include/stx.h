@@ -295,6 +295,23 @@ int stx_vec_axpy_dev(stx_engine *e, double c1, const double *a_dev, double da, d
                      const double *b_dev, double db, const float *x, float *y, size_t n);
 int stx_vec_scale_dev(stx_engine *e, double c, const double *den_dev, double den_div, float *x,
                       size_t n);
+/* Fused passes of the same step (round 5): each computes, value for value and bit for bit, what the
+ * separate calls above compute, and reads an array once where they read it two or three times.
+ *   stx_vec_axpy_dot_dev:   y = coef * x + src (coef as stx_vec_axpy_dev; src may be y); with scale_den_dev
+ *                           != NULL then y *= (float)(scale_c / (*scale_den_dev / scale_div)); *out_dev =
+ *                           <z, y> -- the axpy of one iteration of inv_hv's loops (and the scaling between
+ *                           them) with the dot product of the next (optimizers.py:108-120)
+ *   stx_vec_lbfgs_pair:     y = g_new - g_old, g_old = g_new, out_dev2[0] = <s, y>, out_dev2[1] = <y, y>;
+ *                           *sy_host_sync = out_dev2[0] after a stream synchronisation -- the curvature
+ *                           pair and its test (optimizers.py:84-85,97-103)
+ *   stx_vec_scale2_axpy:    s = c2 * (c1 * s), params += s        (optimizers.py:76-82)              */
+int stx_vec_axpy_dot_dev(stx_engine *e, double c1, const double *a_dev, double da, double c2,
+                         const double *b_dev, double db, double scale_c, const double *scale_den_dev,
+                         double scale_div, const float *x, const float *src, float *y, const float *z,
+                         size_t n, double *out_dev);
+int stx_vec_lbfgs_pair(stx_engine *e, const float *g_new, float *g_old, const float *s, float *y, size_t n,
+                       double *out_dev2, double *sy_host_sync);
+int stx_vec_scale2_axpy(stx_engine *e, double c1, double c2, float *s, float *params, size_t n);
 
 /* Per-step statistics of transfer() (style_transfer.py:808-815):
  * stats[0] = mean|avg - old|, stats[1] = sqrt(mean(xdiff^2 + ydiff^2)) with circular forward

@@ -2184,6 +2184,37 @@ int stx_vec_scale_dev(stx_engine *e, double c, const double *den_dev, double den
     return scale_dev_launch(e->stream, c, den_dev, den_div, x, n);
 }
 
+int stx_vec_axpy_dot_dev(stx_engine *e, double c1, const double *a_dev, double da, double c2,
+                         const double *b_dev, double db, double scale_c, const double *scale_den_dev,
+                         double scale_div, const float *x, const float *src, float *y, const float *z,
+                         size_t n, double *out_dev) {
+    if (!e || !a_dev || !x || !src || !y || !z || !out_dev || da == 0.0 || (b_dev && db == 0.0) ||
+        (scale_den_dev && scale_div == 0.0))
+        return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return axpy_dot_dev_launch(e->stream, c1, a_dev, da, c2, b_dev, db, scale_c, scale_den_dev, scale_div, x,
+                               src, y, z, n, out_dev, e->red_scratch.f(), e->red_scratch.bytes / sizeof(float));
+}
+
+int stx_vec_lbfgs_pair(stx_engine *e, const float *g_new, float *g_old, const float *s, float *y, size_t n,
+                       double *out_dev2, double *sy_host_sync) {
+    if (!e || !g_new || !g_old || !s || !y || !out_dev2 || !sy_host_sync) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    STX_TRY(lbfgs_pair_launch(e->stream, g_new, g_old, s, y, n, out_dev2, e->red_scratch.f(),
+                              e->red_scratch.bytes / sizeof(float)));
+    const size_t di = e->dscalars_cap - 2;   // the pinned mirror's slot for synchronous scalar results
+    STX_HIP(hipMemcpyAsync(e->A().dhost + di, out_dev2, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    STX_HIP(hipStreamSynchronize(e->stream));
+    *sy_host_sync = e->A().dhost[di];
+    return STX_OK;
+}
+
+int stx_vec_scale2_axpy(stx_engine *e, double c1, double c2, float *s, float *params, size_t n) {
+    if (!e || !s || !params) return STX_ERR_ARG;
+    STX_TRY(e->set_device());
+    return scale2_axpy_launch(e->stream, (float)c1, (float)c2, s, params, n);
+}
+
 int stx_vec_axpy(stx_engine *e, double a, const float *x, float *y, size_t n) {
     if (!e || !x || !y) return STX_ERR_ARG;
     STX_TRY(e->set_device());

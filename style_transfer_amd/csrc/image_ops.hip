@@ -622,6 +622,95 @@ int scale_dev_launch(hipStream_t s, double c, const double *den, double den_div,
     return STX_OK;
 }
 
+// Fused passes of the L-BFGS step (round 5).  Each is, value for value, what the separate launches
+// computed -- the same float operations in the same order per element (this file is compiled with
+// -ffp-contract=off), the dot products accumulated by dot_kernel's threads in dot_kernel's order
+// (same grid) and finished by the same kernel -- so a trajectory does not change by one bit; what
+// changes is that an array is read once where it was read two or three times.
+//   y = [g] (f x + src)  (src may be y; g = c_s / (den_s[0] / div_s) when den_s is given),
+//   partial sums of <z, y>                                  [axpy_dev (+ scale_dev) + dot]
+__global__ __launch_bounds__(256) void axpy_dot_dev_kernel(double c1, const double *__restrict__ a,
+                                                           double da, double c2,
+                                                           const double *__restrict__ b, double db,
+                                                           double c_s, const double *__restrict__ den_s,
+                                                           double div_s, const float *__restrict__ x,
+                                                           const float *src, float *y,
+                                                           const float *__restrict__ z, size_t n,
+                                                           float *__restrict__ partials) {
+    double coef = a[0] / da * c1;
+    if (b) coef += b[0] / db * c2;
+    const float f = (float)coef;
+    const bool scaled = den_s != nullptr;
+    const float g = scaled ? (float)(c_s / (den_s[0] / div_s)) : 1.f;
+    float acc[1] = {0.f};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = f * x[i] + src[i];
+        if (scaled) v = g * v;
+        y[i] = v;
+        acc[0] += z[i] * v;
+    }
+    block_partials<1>(acc, partials);
+}
+
+int axpy_dot_dev_launch(hipStream_t s, double c1, const double *a, double da, double c2, const double *b,
+                        double db, double c_s, const double *den_s, double div_s, const float *x,
+                        const float *src, float *y, const float *z, size_t n, double *out_dev, float *scratch,
+                        size_t scratch_floats) {
+    const int blocks = blocks_for(n);
+    if (scratch_floats < (size_t)blocks) return STX_ERR_STATE;
+    axpy_dot_dev_kernel<<<blocks, 256, 0, s>>>(c1, a, da, c2, b, db, c_s, den_s, div_s, x, src, y, z, n, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<1><<<1, 256, 0, s>>>(scratch, blocks, out_dev);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+//   y = -g_old + g_new,  g_old = g_new,  partial sums of <s, y> and <y, y>
+//                                               [copy + axpy(-1) + dot(s, y) + dot(y, y) + copy]
+__global__ __launch_bounds__(256) void lbfgs_pair_kernel(const float *__restrict__ g_new,
+                                                         float *__restrict__ g_old,
+                                                         const float *__restrict__ sv,
+                                                         float *__restrict__ y, size_t n,
+                                                         float *__restrict__ partials) {
+    float acc[2] = {0.f, 0.f};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gn = g_new[i];
+        const float v = -1.0f * g_old[i] + gn;
+        y[i] = v;
+        g_old[i] = gn;
+        acc[0] += sv[i] * v;
+        acc[1] += v * v;
+    }
+    block_partials<2>(acc, partials);
+}
+
+int lbfgs_pair_launch(hipStream_t s, const float *g_new, float *g_old, const float *sv, float *y, size_t n,
+                      double *out_dev2, float *scratch, size_t scratch_floats) {
+    const int blocks = blocks_for(n);
+    if (scratch_floats < (size_t)2 * blocks) return STX_ERR_STATE;
+    lbfgs_pair_kernel<<<blocks, 256, 0, s>>>(g_new, g_old, sv, y, n, scratch);
+    STX_CHECK_LAUNCH();
+    finish_partials_kernel<2><<<1, 256, 0, s>>>(scratch, blocks, out_dev2);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
+//   s = c2 (c1 s),  params = 1 s + params                          [scale + scale + axpy]
+__global__ __launch_bounds__(256) void scale2_axpy_kernel(float c1, float c2, float *__restrict__ sv,
+                                                          float *__restrict__ params, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = c2 * (c1 * sv[i]);
+        sv[i] = v;
+        params[i] = 1.0f * v + params[i];
+    }
+}
+
+int scale2_axpy_launch(hipStream_t s, float c1, float c2, float *sv, float *params, size_t n) {
+    scale2_axpy_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, s>>>(c1, c2, sv, params, n);
+    STX_CHECK_LAUNCH();
+    return STX_OK;
+}
+
 // ------------------------------------------------------------------------------ statistics ---
 __global__ __launch_bounds__(256) void step_stats_kernel(const float *__restrict__ avg,
                                                          float *__restrict__ old, int H, int W,

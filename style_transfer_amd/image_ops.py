@@ -129,6 +129,30 @@ def scale_dev(engine, c, den_ptr, x, den_div=1.0):
     lib.call('stx_vec_scale_dev', engine.handle, float(c), den_ptr, float(den_div), x.ptr, x.size)
 
 
+def axpy_dot_dev(engine, c1, a_ptr, da, x, y, z, out_ptr, c2=0.0, b_ptr=None, db=1.0, src=None,
+                 scale_c=0.0, scale_den_ptr=None, scale_div=1.0):
+    """y = coef * x + src (coef as axpy_dev; src defaults to y), then -- with scale_den_ptr -- y *=
+    float(scale_c / (*scale_den / scale_div)); *out_ptr = <z, y>: the axpy of one iteration of the
+    two-loop recursion (and the scaling between the loops) with the dot product of the next, one pass."""
+    lib.call('stx_vec_axpy_dot_dev', engine.handle, float(c1), a_ptr, float(da), float(c2), b_ptr,
+             float(db), float(scale_c), scale_den_ptr, float(scale_div), x.ptr,
+             (y if src is None else src).ptr, y.ptr, z.ptr, x.size, out_ptr)
+
+
+def lbfgs_pair(engine, g_new, g_old, s, y, out_ptr2):
+    """y = g_new - g_old, g_old = g_new, out_ptr2[0] = <s, y>, out_ptr2[1] = <y, y>; returns <s, y>
+    (one host synchronisation)."""
+    sy = ctypes.c_double()
+    lib.call('stx_vec_lbfgs_pair', engine.handle, g_new.ptr, g_old.ptr, s.ptr, y.ptr, s.size, out_ptr2,
+             ctypes.byref(sy))
+    return sy.value
+
+
+def scale2_axpy(engine, c1, c2, s, params):
+    """s = c2 * (c1 * s); params += s."""
+    lib.call('stx_vec_scale2_axpy', engine.handle, float(c1), float(c2), s.ptr, params.ptr, s.size)
+
+
 def scale(engine, a, x):
     lib.call('stx_vec_scale', engine.handle, float(a), x.ptr, x.size)
 

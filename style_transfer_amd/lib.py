@@ -99,6 +99,9 @@ SIGNATURES = {
     'stx_vec_abs_sum_async': [_vp, _vp, _sz, _vp],
     'stx_vec_axpy_dev': [_vp, _d, _vp, _d, _d, _vp, _d, _vp, _vp, _sz],
     'stx_vec_scale_dev': [_vp, _d, _vp, _d, _vp, _sz],
+    'stx_vec_axpy_dot_dev': [_vp, _d, _vp, _d, _d, _vp, _d, _d, _vp, _d, _vp, _vp, _vp, _vp, _sz, _vp],
+    'stx_vec_lbfgs_pair': [_vp, _vp, _vp, _vp, _vp, _sz, _vp, c_double_p],
+    'stx_vec_scale2_axpy': [_vp, _d, _d, _vp, _vp, _sz],
     'stx_image_step_stats': [_vp, _vp, _vp, _i, _i, c_double_p],
     'stx_image_step_stats_async': [_vp, _vp, _vp, _i, _i, c_double_p],
     'stx_image_to_u8': [_vp, _vp, _i, _i, c_float_p, _vp],

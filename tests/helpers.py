@@ -61,6 +61,19 @@ def cfg4_reference_branches(golden):
     return out
 
 
+def lbfgs_reference_outcomes(golden):
+    """The reference's own outcomes on the e2e_lbfgs fixture (make_golden.py section 4b): the committed
+    run, and the distinct final pictures the same reference code lands on with its convolutions or its
+    Gram matrices rounded as any other float32 kernel rounds them (tests/golden/lbfgs_sensitivity.py ->
+    lbfgs_branches.npz).  [{log [5][4], final_raw, runs}], the committed run first."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lbfgs_branches.npz'))
+    out = [dict(log=np.float64(log), final_raw=raw, runs=int(runs))
+           for log, raw, runs in zip(d['logs'], d['final_raw'], d['runs'])]
+    assert np.array_equal(out[0]['final_raw'], golden['e2e_lbfgs.final_raw'])
+    return out
+
+
 def matching_branch(branches, losses, rtol=2e-4):
     """The reference trajectory whose losses `losses` follows step by step to rtol (None: none of them)."""
     for b in branches:

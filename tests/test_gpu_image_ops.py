@@ -118,6 +118,46 @@ def test_lbfgs_matches_reference_trajectory(golden):
     del tgt, d_scale
 
 
+def test_fused_lbfgs_step_changes_no_bit(monkeypatch):
+    """The fused passes of the L-BFGS step (stx_vec_axpy_dot_dev, stx_vec_lbfgs_pair, stx_vec_scale2_axpy)
+    against one launch per BLAS-1 call: the same iterates bit for bit -- while the memory grows, past
+    n_corr pairs (the oldest dropped), and across a pair the curvature test rejects
+    (optimizers.py:74-121)."""
+    eng = gpu_engine()
+    rng = np.random.RandomState(11)
+    shape = (3, 37, 53)
+    x0 = rng.uniform(-100, 100, shape).astype(np.float32)
+    target = rng.uniform(-100, 100, shape).astype(np.float32)
+    scale = np.exp(rng.uniform(-1.5, 1.5, shape)).astype(np.float32)
+    runs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('STX_LBFGS_FUSED', fused)
+        params = eng.to_device(x0)
+        work = eng.empty(shape)
+        calls = [0]
+
+        def f(x):
+            calls[0] += 1
+            d = (x.get() - target) * scale
+            g = 2 * d * scale
+            if calls[0] == 4:          # the same gradient twice: y = 0, s.y = 0 -> the pair is rejected
+                g = f.last
+            f.last = g
+            work.set(g.astype(np.float32))
+            return float(np.sum(d * d, dtype=np.float64)), work
+        opt = LBFGSOptimizer(eng, params, n_corr=4)
+        assert opt.fused == (fused == '1')
+        trail = []
+        for i in range(12):
+            p, loss = opt.update(f)
+            trail.append((p.get().copy(), loss, len(opt.sk)))
+        runs.append(trail)
+    assert [t[2] for t in runs[0]] == [t[2] for t in runs[1]]
+    assert [t[2] for t in runs[0]] == [1, 2, 2, 3] + [4] * 8
+    for (pa, la, _), (pb, lb, _) in zip(*runs):
+        assert np.array_equal(pa, pb) and la == lb
+
+
 def test_step_stats_and_uint8():
     eng = gpu_engine()
     rng = np.random.RandomState(6)

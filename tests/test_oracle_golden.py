@@ -111,6 +111,23 @@ def test_regularizers_are_additive(golden):
     assert rel_err(grad, 5 * tv_g + 2 * p_g) < 1e-6
 
 
+def test_lbfgs_fixture_outcomes_of_the_reference(golden):
+    """tests/golden/lbfgs_branches.npz (tests/golden/lbfgs_sensitivity.py: the reference's own code on the
+    e2e_lbfgs fixture with its convolutions / Gram matrices rounded as another float32 kernel rounds them):
+    the first outcome IS the committed fixture (and the one most perturbed runs reproduce), the others are
+    distinct pictures that start from the same objective."""
+    from tests.helpers import lbfgs_reference_outcomes
+    outs = lbfgs_reference_outcomes(golden)
+    assert len(outs) >= 3 and sum(o['runs'] for o in outs) >= 20
+    assert np.array_equal(outs[0]['log'], golden['e2e_lbfgs.log']) and outs[0]['runs'] >= 5
+    for i, o in enumerate(outs[1:], 1):
+        assert o['log'].shape == outs[0]['log'].shape and o['final_raw'].shape == outs[0]['final_raw'].shape
+        rel = np.abs(o['log'][:, 2] / outs[0]['log'][:, 2] - 1)
+        assert rel[0] < 1e-6 and rel.max() < 1e-2
+        for q in outs[:i]:                       # pairwise distinct pictures
+            assert np.abs(o['final_raw'] - q['final_raw']).max() >= 0.05
+
+
 def test_config4_miniature_branches_of_the_reference(golden):
     """tests/golden/cfg4_branches.npz (tests/golden/cfg4_sensitivity.py: the reference's own code on the
     config-4 miniature with its convolutions rounded as another float32 kernel rounds them): the first
