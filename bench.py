@@ -382,6 +382,19 @@ def whole_run_wall_clock(devices):
 # C * C * h * w = 2^32 / 2^20 per tile pixel for conv1_1 .. conv4_1 (a quarter of that for conv5_1)
 GRAM_SYMM_FLOP_PER_TILE_PIXEL = int(2 * 2 * 4096 * (4 + 0.25))
 BF16X3_PIPE_TIME = 6 * 32 / (8 * 64)    # six bf16 MFMAs (32 cycles) per 16 k instead of eight fp32 ones (64)
+F16X2_PIPE_TIME = 3 * 32 / (8 * 64)     # three fp16 MFMAs per 16 k (two-piece operands, round 5)
+
+
+def terms_pipe_time():
+    """Pipe time of a tile's Gram + SYMM products as a fraction of their fp32-MFMA form's: the two-piece
+    fp16 kernels by default (STX_GRAM / STX_SYMM = bf3 | fp32: the three-piece bf16 / the fp32 kernels);
+    the Gram of conv1_1 is computed by the first layer's kernel with three bf16 pieces (4 of the 17 quarter
+    units of the five Gram products: 4 + 4 + 4 + 4 + 1)."""
+    rate = {'fp32': 1.0, 'bf3': BF16X3_PIPE_TIME}
+    gram = rate.get(os.environ.get('STX_GRAM'), F16X2_PIPE_TIME)
+    symm = rate.get(os.environ.get('STX_SYMM'), F16X2_PIPE_TIME)
+    first = BF16X3_PIPE_TIME if os.environ.get('STX_CONV_FIRST_FUSED') != '0' else gram
+    return 0.5 * (first * 4 / 17 + gram * 13 / 17) + 0.5 * symm
 
 
 def clock_summary(engines):
@@ -426,16 +439,15 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
     matrix pipe, expressed in fp32-MFMA FLOP: fp32 Winograd convolutions issue 4/9 (2-D) or 2/3 (1-D)
     of a direct convolution's fp32 MFMAs; the fp16-split convolutions (conv_h2.hip) three fp16 MFMAs
     per 16 k for 6 of every 9 multiplies, i.e. 1/8 of a direct convolution's fp32 pipe time; Gram and
-    SYMM issue six bf16 MFMAs per 16 k, which occupy the pipe for 0.375 of the time their fp32 form
-    would -- so frac <= 1 by construction."""
+    SYMM issue three fp16 MFMAs per 16 k (round 5; the Gram of conv1_1 six bf16 ones), which occupy the
+    pipe for 0.1875 (0.375) of the time their fp32 form would -- so frac <= 1 by construction."""
     flop = FLOP_PER_TILE_PIXEL * TILE * TILE * tiles_per_gpu
     direct_equiv = flop / (avg_group_ms * 1e-3) / 1e12
     conv_alg, conv_issued = eng.last_tile_flops()
     terms = GRAM_SYMM_FLOP_PER_TILE_PIXEL * TILE * TILE
-    bf16_terms = os.environ.get('STX_GRAM') != 'fp32' and os.environ.get('STX_SYMM') != 'fp32'
     per_tile = flop / tiles_per_gpu - conv_alg - terms + conv_issued
     issued_r02 = (per_tile + terms) * tiles_per_gpu            # round-2 accounting: terms at the fp32 rate
-    issued = (per_tile + terms * (BF16X3_PIPE_TIME if bf16_terms else 1.0)) * tiles_per_gpu
+    issued = (per_tile + terms * terms_pipe_time()) * tiles_per_gpu
     issued_tflops = issued / (avg_group_ms * 1e-3) / 1e12
     bound_ms = issued / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
     traffic, traffic_src = measured_traffic(tiles_per_gpu)
@@ -448,13 +460,12 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
             'bound_ms': bound_ms, 'bound_ms_per_tile': bound_ms / tiles_per_gpu,
             'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
-            'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_h2_kernel<0|1|3,2> (3x3 layers '
-                      'from 128 input channels forward, from 64 backward: fp16 MFMA, two-piece operand '
-                      'split, fp32 accumulate; forward / backward / loss-injecting backward; half of the '
-                      'time), conv_wino2_kernel<0|3,32> (the 64-channel layers forward, conv1_2 backward: '
-                      'fp32 MFMA), conv_first_kernel (first layer + its Gram partials), conv3x3_m4_kernel '
-                      '(backward into the image), gram_partial_bf3_kernel / symm_bf3_kernel (bf16 MFMA, '
-                      'three-piece split)' % tiles_per_gpu,
+            'kernel': 'stx_sc_grad_tile x %d concurrent on one GPU: conv_h2_kernel<0|1|3, 1|2, 1|2> (every 3x3 '
+                      'layer from 64 input channels, forward / backward / loss-injecting backward: fp16 MFMA, '
+                      'two-piece operand split, fp32 accumulate; three quarters of the kernel time), '
+                      'conv_first_kernel (first layer + its Gram partials), conv3x3_m4_kernel (backward into '
+                      'the image), gram_partial_h2_kernel / symm_h2_kernel (fp16 MFMA, two-piece split)'
+                      % tiles_per_gpu,
             'flop_issued_per_launch': issued, 'avg_launch_ms': avg_group_ms,
             'achieved_direct_equiv': direct_equiv,
             'flop_direct_equiv_per_launch': flop,
@@ -462,8 +473,9 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
                     'priced in fp32-MFMA FLOP (fp32 Winograd F(2x2,3x3) convolutions issue 4/9 of a direct '
                     'convolution; the fp16-split 1-D Winograd convolutions three fp16 MFMAs of 1/16 of an '
                     'fp32 MFMA\'s time per k for 6 of 9 multiplies = 1/8 of a direct convolution\'s pipe '
-                    'time; Gram and SYMM six bf16 MFMAs per 16 k = 0.375 of the pipe time of their fp32 '
-                    'form) over the HIP-event time of the launch group, against the fp32 '
+                    'time; Gram and SYMM three fp16 MFMAs per 16 k = 0.1875 of the pipe time of their fp32 '
+                    'form, the Gram of conv1_1 six bf16 ones = 0.375) over the HIP-event time of the launch '
+                    'group, against the fp32 '
                     'MFMA peak at 2.4 GHz: the fraction of that time the matrix pipes are busy at the '
                     'nominal clock; frac_driver_clock = the same work over the wall-clock '
                     'ms_per_step; clock_mhz is the shader clock INSIDE the Winograd convolution '

@@ -420,6 +420,14 @@ int scale_launch(hipStream_t s, float a, float *x, size_t n);
 int axpy_dev_launch(hipStream_t s, double c1, const double *a, double da, double c2, const double *b,
                     double db, const float *x, float *y, size_t n);
 int scale_dev_launch(hipStream_t s, double c, const double *den, double den_div, float *x, size_t n);
+// fused passes of the L-BFGS step (image_ops.hip): bit for bit the separate launches they replace
+int axpy_dot_dev_launch(hipStream_t s, double c1, const double *a, double da, double c2, const double *b,
+                        double db, double c_s, const double *den_s, double div_s, const float *x,
+                        const float *src, float *y, const float *z, size_t n, double *out_dev, float *scratch,
+                        size_t scratch_floats);
+int lbfgs_pair_launch(hipStream_t s, const float *g_new, float *g_old, const float *sv, float *y, size_t n,
+                      double *out_dev2, float *scratch, size_t scratch_floats);
+int scale2_axpy_launch(hipStream_t s, float c1, float c2, float *sv, float *params, size_t n);
 int step_stats_launch(hipStream_t s, const float *avg, float *old, int H, int W,
                       double *out_dev /*[2]*/, float *scratch, size_t scratch_floats);
 int to_u8_launch(hipStream_t s, const float *img, int H, int W, const float mean[3], uint8_t *out);

@@ -90,7 +90,7 @@ class LBFGSOptimizer:
     with both of its dot products and the copy of the gradient, the step's two scalings with its
     addition to the image.  Every value is computed by the same float operations in the same
     order (the dot products by the same threads in the same grid), so the trajectory is the
-    unfused one bit for bit; the step moves 92 array passes instead of 121 at a full memory."""
+    unfused one bit for bit; the step moves 89 array passes instead of 119 at a full memory."""
 
     def __init__(self, engine, params, initial_step=0.1, n_corr=10):
         import os
