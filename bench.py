@@ -92,8 +92,8 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
-TRAFFIC_PROFILE = 'profiles/r05_hbm_traffic_pmc.json'
-TRAFFIC_PROFILE_FALLBACK = 'profiles/r03_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE = 'profiles/r05b_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE_FALLBACK = 'profiles/r05_hbm_traffic_pmc.json'
 
 
 def measured_traffic(tiles_per_launch):
