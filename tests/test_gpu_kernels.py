@@ -168,6 +168,39 @@ def test_style_terms_match_reference_fixtures(golden):
     assert max_rel(s_out.get(), num_ops.symm_lower_times(gd, feat.reshape(c, -1))) < 2e-5
 
 
+@pytest.mark.parametrize('variant', ['', 'bf3'])
+@pytest.mark.parametrize('c,h,w,big', [(68, 9, 11, 1.0), (96, 17, 13, 3e4), (192, 8, 8, 1e-6), (320, 5, 7, 1.0), (64, 40, 50, 1e8)])
+def test_style_terms_over_channel_counts_and_ranges(c, h, w, big, variant, monkeypatch):
+    """The style branch on channel counts that are no multiple of 64 (rows and columns of G - Gs past C
+    read as zero inside the SYMM kernel), odd plane sizes, and features from 1e-6 to 1e8 (float32 holds the
+    squares of G - Gs up to there; the fp16
+    two-piece kernels scale by the operands' own maxima: nothing may overflow or vanish) -- against
+    float64, at the kernel tests' 2e-5 of max; `bf3`: the three-piece bf16 kernels on the same data."""
+    import ctypes
+    if variant:
+        monkeypatch.setenv('STX_GRAM', variant)
+        monkeypatch.setenv('STX_SYMM', variant)
+    eng = gpu_engine()
+    rng = np.random.RandomState(c + h)
+    feat = (np.maximum(rng.standard_normal((c, h, w)), 0) * big).astype(np.float32)
+    feat[rng.randint(c), rng.randint(h), rng.randint(w)] *= 37.0            # one value far above the rest
+    f64 = feat.reshape(c, -1).astype(np.float64)
+    g = np.tril(f64 @ f64.T / f64.size)
+    target = (g * np.tril(rng.uniform(0.5, 1.5, (c, c)))).astype(np.float32)
+    d = np.tril(g - target)
+    s_ref = (d + np.tril(d, -1).T) @ f64
+    d_feat, d_tgt = eng.to_device(feat), eng.to_device(target)
+    s_out = eng.empty((c, h * w))
+    half, asum = ctypes.c_double(), ctypes.c_double()
+    lib.call('stx_op_style_terms', eng.handle, d_feat.ptr, c, h, w, d_tgt.ptr, s_out.ptr, None,
+             ctypes.byref(half), ctypes.byref(asum))
+    got = s_out.get().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - s_ref).max() <= 2e-5 * np.abs(s_ref).max()
+    assert half.value == pytest.approx(0.5 * float((d * d).sum()), rel=2e-5)
+    assert asum.value == pytest.approx(float(np.abs(s_ref).sum()), rel=2e-5)
+
+
 def test_content_terms_match_reference_normalize(golden):
     """F - Fc window sums and the normalized residual; with Fc = 0 this is num_utils.normalize /
     norm2 / sasum on the fixture itself (num_utils.py:69-71,85-87)."""
