@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         const_cast<float *>(a.inj.feat), 0, a.inj.feat ? (int)plane_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.bias), 0, a.bias ? a.M * 4 : 0, 0x00020000);
-    const int ph = (a.H + 1) >> 1, pw = a.W >> 1;
+    const int ph = (a.H + 1) >> 1, pw = (a.W + 1) >> 1;      // (ceil mode: an odd plane's last window has one column)
     const __amdgpu_buffer_rsrc_t rpool = __builtin_amdgcn_make_buffer_rsrc(
         a.pool_out, 0, a.pool_out ? a.M * ph * pw * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rcodes = __builtin_amdgcn_make_buffer_rsrc(
@@ -796,20 +796,23 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 // the lane's 2x2 outputs are one window of the 2x2/2 pooling layer that follows
                 // (pool.hip's arithmetic; ceil mode: the second row may be missing)
                 if (EPI == kEpiForward && a.pool_out) {
-                    const bool hy = lr.yy + 1 < a.H;
+                    // (hx: the window's second column exists -- always on even planes)
+                    const bool hy = lr.yy + 1 < a.H, hx = decltype(even_c)::value || xx0 + 1 < a.W;
                     float pr;
                     if (a.pool_mode == STX_POOL_MAX) {
-                        pr = fmaxf(v[0].x, v[0].y);
-                        pr = hy ? fmaxf(fmaxf(pr, v[1].x), v[1].y) : pr;
+                        pr = hx ? fmaxf(v[0].x, v[0].y) : v[0].x;
+                        if (hy) pr = hx ? fmaxf(fmaxf(pr, v[1].x), v[1].y) : fmaxf(pr, v[1].x);
                     } else {
-                        pr = (v[0].x + v[0].y + (hy ? v[1].x : 0.f) + (hy ? v[1].y : 0.f)) * (hy ? 0.25f : 0.5f);
+                        // (the sum in pool.hip's order, the divisor the number of elements the clipped window has)
+                        pr = (v[0].x + (hx ? v[0].y : 0.f) + (hy ? v[1].x : 0.f) + (hx && hy ? v[1].y : 0.f)) *
+                             (hy ? (hx ? 0.25f : 0.5f) : (hx ? 0.5f : 1.0f));
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pr), rpool, lr.vpool,
                                                           (unsigned)c * (unsigned)(ph * pw * 4), 0);
                     if (a.pool_codes) {
                         const unsigned code = a.pool_mode == STX_POOL_MAX
-                                                  ? pool_max_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy)
-                                                  : pool_ave_code(v[0].x, v[0].y, v[1].x, v[1].y, true, hy);
+                                                  ? pool_max_code(v[0].x, v[0].y, v[1].x, v[1].y, hx, hy)
+                                                  : pool_ave_code(v[0].x, v[0].y, v[1].x, v[1].y, hx, hy);
                         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)code, rcodes, lr.vpool >> 2,
                                                              (unsigned)c * (unsigned)(ph * pw), 0);
                     }
@@ -1054,8 +1057,8 @@ bool h2_takes_pooled_input(const ConvConfig &cfg, const ConvProblem &p) {
 }
 
 bool h2_fuses_pool(const ConvProblem &p) {
-    return p.pool_out && p.epilogue == kEpiForward && (p.W & 1) == 0 &&
-           (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
+    // (odd planes too: the last window of a row has one column, as the last of a column may have one row)
+    return p.pool_out && p.epilogue == kEpiForward && (((size_t)p.y | (size_t)p.pool_out) & 7) == 0;
 }
 
 template <int EPI, int MB, int PB, int PIN = 0>

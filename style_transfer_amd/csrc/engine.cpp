@@ -515,6 +515,9 @@ static bool conv_writes_pool_codes(const ConvConfig &cfg) { return (cfg.id >= 20
 
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
+    // (STX_POOL_FWD_FUSE=0: the stand-alone pooling kernel everywhere, for A/B measurements and tests)
+    const char *env = getenv("STX_POOL_FWD_FUSE");
+    if (env && atoi(env) == 0) return false;
     if (cfg.id >= 300) return conv_splitk_factor(cfg, p, true) == 1 && h2_fuses_pool(p);
     return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
 }

@@ -265,3 +265,43 @@ def test_pooling_backward_inside_the_next_convolution(model, th, tw, monkeypatch
     assert skipped['1'] >= (1 if th * tw < 10000 else 2), skipped
     assert out['1'][0] == out['0'][0]
     assert np.array_equal(out['1'][1], out['0'][1])
+
+
+@pytest.mark.parametrize('model,th,tw', [('vgg19', 203, 331), ('vgg16_avgpool', 131, 277), ('vgg19', 256, 384),
+                                         ('vgg16_avgpool', 90, 61)])
+def test_pooling_forward_inside_the_convolution_epilogue(model, th, tw, monkeypatch):
+    """The 2x2/2 pooling layer behind a convolution runs in that convolution's epilogue (a lane's 2 x 2
+    outputs are one window) -- since round 5 on odd planes too, where the last window of a row has one
+    column as the last of a column may have one row (ceil mode: MAX over what exists, AVE with the clipped
+    window's divisor).  pool.hip's arithmetic on the same values: against STX_POOL_FWD_FUSE=0 (the
+    stand-alone kernel) loss, gradient and every pooled blob are BIT-IDENTICAL."""
+    from style_transfer_amd.engine import TileEngine
+    from tests.gpu_helpers import builtin_net, require_gpu, synthetic_weights
+    require_gpu()
+    net = builtin_net(model)
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(tw)
+    tile = rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)
+    cl, sl = ['conv4_2'], ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+    cw, sw = {'conv4_2': 0.05}, {l: 0.2 for l in sl}
+    pools = ['pool1', 'pool2', 'pool3', 'pool4']
+    out, standalone = {}, {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('STX_POOL_FWD_FUSE', fuse)
+        eng = TileEngine(net, 0, weights)
+        r = np.random.RandomState(3)
+        eng.set_contents_and_styles(
+            [{l: np.abs(r.standard_normal(eng.feature_shape(l, th, tw))).astype(np.float32) for l in cl}],
+            [{l: np.tril(r.standard_normal((eng.layer_info(l)[1],) * 2)).astype(np.float32) for l in sl}])
+        eng.profile(True)
+        loss, grad = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        standalone[fuse] = sum(row[0].startswith('fwd pool') for row in eng.profile_read())
+        eng.profile(False)
+        out[fuse] = (loss, grad, eng.features_tile(tile, pools))
+        eng.close()
+    assert standalone['0'] == 4
+    # (planes whose convolution splits its reduction keep the stand-alone kernel)
+    assert standalone['1'] <= (2 if th * tw > 10000 else 3), standalone
+    assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1])
+    for name in pools:
+        assert np.array_equal(out['1'][2][name], out['0'][2][name]), name
