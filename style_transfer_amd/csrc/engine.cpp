@@ -803,7 +803,8 @@ int forward(stx_engine *e, const std::vector<char> &needed, int relu_blob,
     int pooled_layer = -1;      // pooling layer whose output the producing convolution wrote
     // the maxima the fp16-split convolutions leave for each other (Blob::amax_data): none yet
     STX_TRY(e->amax.ensure((2 * e->blobs.size() + 2) * kAmaxSlots * sizeof(unsigned)));
-    STX_HIP(hipMemsetAsync(e->amax_slots(0, false), 0, e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
+    // (the data slots and, behind them, the diff slots of a backward walk that may follow: one fill)
+    STX_HIP(hipMemsetAsync(e->amax_slots(0, false), 0, 2 * e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
     for (Blob &b : e->blobs) {
         b.amax_data = -1;
         b.relu_codes_valid = false;
@@ -1850,7 +1851,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
 
     // ---- backward walk from the deepest tap to the image (style_transfer.py:569-610)
     int cur = order[0].blob;
-    STX_HIP(hipMemsetAsync(e->amax_slots(0, true), 0, e->blobs.size() * kAmaxSlots * sizeof(unsigned), e->stream));
+    // (the diff slots were zeroed with the data slots when the forward pass began)
     for (Blob &b : e->blobs) b.amax_diff = -1;
     {
         bool written = false;
