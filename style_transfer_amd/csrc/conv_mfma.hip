@@ -491,16 +491,17 @@ __device__ __forceinline__ float splitk_reduce_element(const SplitReduceArgs &a,
                                                        float c_scale) {
     float v = a.part[i];
     for (int k = 1; k < a.ksplit; ++k) v += a.part[(size_t)k * n + i];
-    const int m = i / a.HW;
+    // (plane sets stay under 2^32 elements: a 32-bit division instead of a 64-bit one per element)
+    const int m = (int)((unsigned)i / (unsigned)a.HW);
     if (a.epilogue == kEpiForward) {
         if (a.bias) v += a.bias[m];
         if (a.relu) v = fmaxf(v, 0.f);
     } else {
         if (a.mask) v = a.mask[i] > 0.f ? v : 0.f;
         if (a.inj.content) {
-            const int pix = i - (size_t)m * a.HW;
+            const unsigned pix = (unsigned)i - (unsigned)m * (unsigned)a.HW;
             v += c_scale * (a.inj.feat[i] -
-                            a.inj.content[content_index(a.inj.win, m, pix / a.W, pix % a.W)]);
+                            a.inj.content[content_index(a.inj.win, m, (int)(pix / (unsigned)a.W), (int)(pix % (unsigned)a.W))]);
         }
         if (a.inj.sgrad) v += s_scale * a.inj.sgrad[i];
     }
@@ -519,6 +520,61 @@ __device__ __forceinline__ void splitk_reduce_amax(const SplitReduceArgs &a, flo
     if (threadIdx.x == 0)
         atomicMax(a.y_amax + (blockIdx.x & (kAmaxSlots - 1)),
                   __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+// Four consecutive elements per thread (plane sizes that are a multiple of 4: the four share their
+// channel; 16-byte accesses, the slices of a vector requested four at a time).  Every element is the sum
+// of its slices in slice order, then the epilogue of splitk_reduce_element: the same bits.
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void splitk_reduce_vec4_kernel(SplitReduceArgs a) {
+    const unsigned n = (unsigned)a.M * (unsigned)a.HW, n4 = n >> 2;
+    float s_scale = 0.f, c_scale = 0.f;
+    if (a.inj.sgrad) s_scale = a.inj.s_coef * (1.0f / (a.inj.s_abs_sum[0] / (float)n + kEps));
+    if (a.inj.content) c_scale = a.inj.c_coef * (1.0f / (a.inj.c_sums[1] / (float)n + kEps));
+    float amax = 0.f;
+    const f32x4r *part = reinterpret_cast<const f32x4r *>(a.part);
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < n4; q += gridDim.x * 256u) {
+        f32x4r v = part[q];
+        int k = 1;
+        for (; k + 3 < a.ksplit; k += 4) {
+            const f32x4r p0 = part[(size_t)k * n4 + q], p1 = part[(size_t)(k + 1) * n4 + q];
+            const f32x4r p2 = part[(size_t)(k + 2) * n4 + q], p3 = part[(size_t)(k + 3) * n4 + q];
+            v += p0;
+            v += p1;
+            v += p2;
+            v += p3;
+        }
+        for (; k < a.ksplit; ++k) v += part[(size_t)k * n4 + q];
+        const unsigned i = q << 2, m = i / (unsigned)a.HW;
+        if (a.epilogue == kEpiForward) {
+            if (a.bias) v += a.bias[m];
+            if (a.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        } else {
+            if (a.mask) {
+                const f32x4r mk = reinterpret_cast<const f32x4r *>(a.mask)[q];
+                v.x = mk.x > 0.f ? v.x : 0.f, v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f, v.w = mk.w > 0.f ? v.w : 0.f;
+            }
+            if (a.inj.content) {
+                const f32x4r ft = reinterpret_cast<const f32x4r *>(a.inj.feat)[q];
+                const unsigned pix = i - m * (unsigned)a.HW;
+                float cv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cv[e] = a.inj.content[content_index(a.inj.win, (int)m, (int)((pix + e) / (unsigned)a.W),
+                                                        (int)((pix + e) % (unsigned)a.W))];
+                v.x += c_scale * (ft.x - cv[0]), v.y += c_scale * (ft.y - cv[1]);
+                v.z += c_scale * (ft.z - cv[2]), v.w += c_scale * (ft.w - cv[3]);
+            }
+            if (a.inj.sgrad) {
+                const f32x4r sg = reinterpret_cast<const f32x4r *>(a.inj.sgrad)[q];
+                v.x += s_scale * sg.x, v.y += s_scale * sg.y, v.z += s_scale * sg.z, v.w += s_scale * sg.w;
+            }
+        }
+        reinterpret_cast<f32x4r *>(a.y)[q] = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    splitk_reduce_amax(a, amax);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduceArgs a) {
@@ -711,6 +767,22 @@ static SplitReduceArgs splitk_reduce_args(const ConvProblem &p, int ksplit) {
 int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
     const SplitReduceArgs r = splitk_reduce_args(p, ksplit);
     const size_t n = (size_t)p.M * p.H * p.W;
+    if (n >= ((size_t)1 << 32)) {      // (the kernels index one plane set with 32 bits; only small planes split)
+        set_error("splitk_reduce: %zu elements", n);
+        return STX_ERR_UNSUPPORTED;
+    }
+    // four elements per thread where a vector stays inside one channel and every array is 16-byte aligned
+    // (STX_REDUCE_VEC=0: the element-wise kernel; bit-identical either way)
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(r.part) | reinterpret_cast<uintptr_t>(r.y) |
+                           reinterpret_cast<uintptr_t>(r.mask) | reinterpret_cast<uintptr_t>(r.inj.feat) |
+                           reinterpret_cast<uintptr_t>(r.inj.sgrad);
+    const char *env = getenv("STX_REDUCE_VEC");
+    if ((p.H * p.W) % 4 == 0 && (ptrs & 15) == 0 && n < (1u << 31) && !(env && atoi(env) == 0)) {
+        const size_t n4 = n / 4;
+        splitk_reduce_vec4_kernel<<<(int)std::min<size_t>((n4 + 255) / 256, p.y_amax ? 1024 : 4096), 256, 0, s>>>(r);
+        STX_CHECK_LAUNCH();
+        return STX_OK;
+    }
     // (with y_amax every block ends in an atomic on one of kAmaxSlots words: fewer, longer blocks)
     splitk_reduce_kernel<<<(int)std::min<size_t>((n + 255) / 256, p.y_amax ? 1024 : 4096), 256, 0, s>>>(r);
     STX_CHECK_LAUNCH();
@@ -720,6 +792,10 @@ int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
 int splitk_reduce_items_launch(hipStream_t s, const ConvProblem &p, const ConvConfig &cfg, int slices,
                                int item_base, int items) {
     const SplitReduceArgs r = splitk_reduce_args(p, slices);
+    if ((size_t)p.M * p.H * p.W >= ((size_t)1 << 32)) {
+        set_error("splitk_reduce: %zu elements", (size_t)p.M * p.H * p.W);
+        return STX_ERR_UNSUPPORTED;
+    }
     ItemRange range;
     range.item_base = item_base;
     range.m_tiles = ceil_div(p.M, 64);

@@ -305,3 +305,32 @@ def test_pooling_forward_inside_the_convolution_epilogue(model, th, tw, monkeypa
     assert out['1'][0] == out['0'][0] and np.array_equal(out['1'][1], out['0'][1])
     for name in pools:
         assert np.array_equal(out['1'][2][name], out['0'][2][name]), name
+
+
+@pytest.mark.parametrize('model,th,tw', [('vgg19', 256, 256), ('vgg16_avgpool', 128, 192), ('vgg19', 64, 96)])
+def test_vectorised_k_slice_reduce_changes_no_bit(model, th, tw, monkeypatch):
+    """The pass that adds the K slices of a split convolution up (bias + ReLU, or mask + loss terms) takes
+    four elements per thread where the plane size allows: every element is still the sum of its slices in
+    slice order -- against STX_REDUCE_VEC=0 (one element per thread) loss and gradient are BIT-IDENTICAL,
+    content- and style-injecting layers included (small planes: most layers of these tiles split)."""
+    from style_transfer_amd.engine import TileEngine
+    from tests.gpu_helpers import builtin_net, require_gpu, synthetic_weights
+    require_gpu()
+    net = builtin_net(model)
+    weights = synthetic_weights(net.as_dicts(), 0)
+    rng = np.random.RandomState(th + tw)
+    tile = rng.uniform(-110, 120, (3, th, tw)).astype(np.float32)
+    cl, sl = ['conv4_2'], ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1']
+    cw, sw = {'conv4_2': 0.05}, {l: 0.2 for l in sl}
+    out, reduces = {}, {}
+    for vec in ('0', '1'):
+        monkeypatch.setenv('STX_REDUCE_VEC', vec)
+        eng = TileEngine(net, 0, weights)
+        r = np.random.RandomState(3)
+        eng.set_contents_and_styles(
+            [{l: np.abs(r.standard_normal(eng.feature_shape(l, th, tw))).astype(np.float32) for l in cl}],
+            [{l: np.tril(r.standard_normal((eng.layer_info(l)[1],) * 2)).astype(np.float32) for l in sl}])
+        out[vec] = eng.sc_grad_tile(tile, (0, 0), (0, 0), cl, sl, {}, cw, sw)
+        eng.close()
+    assert out['1'][0] == out['0'][0]
+    assert np.array_equal(out['1'][1], out['0'][1])
