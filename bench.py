@@ -67,6 +67,7 @@ sys.path.insert(0, REPO)
 TILE = 1024
 FLOP_PER_TILE_PIXEL = 1514240          # VGG-19, default taps: fwd + dgrad + Gram + SYMM
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+PEAK_FP16_MFMA_TFLOPS = 16 * PEAK_FP32_MFMA_TFLOPS    # v_mfma_f32_32x32x16_f16: 16 k per 32 cycles against 2 k per 64 (the guide's ~2.5 PFLOP/s dense)
 NOMINAL_CLOCK_MHZ = 2400.0
 # the arithmetic the path computes in: float32 values throughout; the 3x3 layers from 128 channels up
 # form their products on the fp16 matrix cores from two-piece operands (22 significand bits) and add
@@ -92,8 +93,8 @@ def smooth_picture(seed, h, w):
     return np.ascontiguousarray(big.transpose(2, 0, 1)[::-1] - np.float32(MEAN).reshape(3, 1, 1))
 
 
-TRAFFIC_PROFILE = 'profiles/r05b_hbm_traffic_pmc.json'
-TRAFFIC_PROFILE_FALLBACK = 'profiles/r05_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE = 'profiles/r06_hbm_traffic_pmc.json'
+TRAFFIC_PROFILE_FALLBACK = 'profiles/r05b_hbm_traffic_pmc.json'
 
 
 def measured_traffic(tiles_per_launch):
@@ -453,6 +454,11 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
     traffic, traffic_src = measured_traffic(tiles_per_gpu)
     return {'bound': 'mfma', 'achieved': issued_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
+            # the same fraction stated against the pipe it is really measured on: pipe time is pipe time, so
+            # x fp32-MFMA-equivalent TFLOP/s of 157.3 = 16 x of the fp16 pipe's 2 516.8 (with the fp16-split
+            # kernels nearly all of the issued work IS fp16 MFMAs)
+            'peak_fp16': PEAK_FP16_MFMA_TFLOPS, 'achieved_fp16_equiv': 16 * issued_tflops,
+            'frac_fp16_pipe': issued_tflops / PEAK_FP32_MFMA_TFLOPS,
             # the same work over the wall-clock step (cut, stitch, regularizers, Adam, statistics
             # and the host's share included): what the driver's own clock sees
             'frac_driver_clock': issued / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -493,6 +499,112 @@ def roofline_record(eng, avg_group_ms, tiles_per_gpu, ms_per_step):
                     'profile named in traffic_source, not a measurement of this run'}
 
 
+def kernel_records(job, reps=5):
+    """Per-kernel-group figures of ONE 1024 x 1024 tile evaluation on one stream, measured in this run
+    (stx_profile_read: HIP events around every launch group inside the engine), after the timed legs:
+    `dominant` -- the kernel that takes most of a tile's time, conv_h2_kernel<0,2,1,0> (the forward 3x3 layers
+    from 128 input channels: conv2_2 .. conv5_1) --, `furthest_below` -- the launch group with the lowest
+    fraction of its pipe --, and the groups' shares.  Issued FLOP of an fp16-split layer = 2 x its direct
+    count (6 of 9 multiplies x 3 fp16 products), against the fp16 MFMA peak."""
+    eng = job.eng
+    tile = eng.to_device(smooth_picture(9, TILE, TILE))
+    grad = eng.empty((3, TILE, TILE))
+    args = ((0, 0), (0, 0), CONTENT_LAYERS, STYLE_LAYERS, {}, CONTENT_WEIGHT, STYLE_WEIGHT)
+    for _ in range(2):
+        eng.sc_grad_tile_async(tile, *args, grad_out=grad)
+    eng.sync()
+    eng.profile(True)
+    acc, order = {}, []
+    for _ in range(reps):
+        eng.sc_grad_tile_async(tile, *args, grad_out=grad)
+        for label, ms, flops in eng.profile_read():
+            if label not in acc:
+                acc[label] = [0.0, flops]
+                order.append(label)
+            acc[label][0] += ms / reps
+    eng.profile(False)
+    tile.free()
+    grad.free()
+    h2_min = int(os.environ.get('STX_CONV_H2', '64') or 0)
+    groups = {}
+
+    def add(group, label, ms, issued):
+        g = groups.setdefault(group, {'launch_groups': [], 'ms_per_tile': 0.0, 'flop_issued_fp16': 0.0})
+        g['launch_groups'].append(label)
+        g['ms_per_tile'] += ms
+        g['flop_issued_fp16'] += issued
+    total = 0.0
+    for label in order:
+        ms, direct = acc[label]
+        total += ms
+        kind, _, layer = label.partition(' ')
+        if kind in ('fwd', 'bwd') and layer.startswith('conv') and direct > 0:
+            scale, cout = eng.layer_info(layer)
+            cin = int(round(direct / (18.0 * cout * (TILE // scale) ** 2)))
+            k_in = cin if kind == 'fwd' else cout          # channels the launch reduces over
+            if min(cin, cout) < 8:
+                add('first layer / backward into the image (fp32 MFMA)', label, ms, 0.0)
+            elif h2_min and k_in >= max(h2_min, 128) and min(cin, cout) >= 128:
+                # (a backward launch adds the loss terms of the blob whose gradient it writes: convX_Y's is convX_(Y-1))
+                x, _, y = layer[4:].partition('_')
+                inject = kind == 'bwd' and 'conv%s_%d' % (x, int(y) - 1) in STYLE_LAYERS + CONTENT_LAYERS
+                add('%s 3x3 layers from 128 channels (conv_h2_kernel<%s,2,1,*>)'
+                    % ('forward' if kind == 'fwd' else 'loss-injecting backward' if inject else 'backward',
+                       '0' if kind == 'fwd' else '3' if inject else '1'), label, ms, 2 * direct)
+            elif h2_min and k_in >= h2_min:
+                add('64-channel layers: %s (conv_h2_kernel, 64-channel or two-patch tilings)' % label, label, ms, 2 * direct)
+            else:
+                add('fp32 convolution: ' + label, label, ms, 0.0)
+        else:
+            add('loss terms, pooling, copies', label, ms, 0.0)
+    rows = []
+    for name, g in groups.items():
+        tf = g['flop_issued_fp16'] / (g['ms_per_tile'] * 1e-3) / 1e12 if g['ms_per_tile'] > 0 else 0.0
+        rows.append({'name': name, 'launch_groups': len(g['launch_groups']), 'ms_per_tile': g['ms_per_tile'],
+                     'share_of_tile': g['ms_per_tile'] / total, 'flop_issued_fp16': g['flop_issued_fp16'],
+                     'tflops_issued': tf, 'frac_fp16_pipe': tf / PEAK_FP16_MFMA_TFLOPS})
+    matrix = [r for r in rows if r['flop_issued_fp16'] > 0]
+    out = {'tile_ms_single_stream': total, 'groups': rows,
+           'note': 'one tile evaluation alone on one stream (the timed steps run two at a time): HIP events around '
+                   'every launch group, mean of %d evaluations; issued FLOP of an fp16-split layer = 2 x direct; '
+                   'frac_fp16_pipe against %.1f TFLOP/s' % (reps, PEAK_FP16_MFMA_TFLOPS)}
+    if matrix:
+        out['dominant'] = max(matrix, key=lambda r: r['ms_per_tile'])
+        out['furthest_below'] = min(matrix, key=lambda r: r['frac_fp16_pipe'])
+    return out
+
+
+FP32_KERNELS = {'STX_CONV_H2': '0', 'STX_GRAM': 'fp32', 'STX_SYMM': 'fp32', 'STX_STREAMS_PER_GPU': '4'}
+
+
+def fp32_kernels_leg(opts, net, weights, device_index, rows, cols):
+    """The same step loop with the fp32-MFMA kernels only (no fp16-split convolution, Gram or SYMM: round 4's
+    arithmetic, on the four streams per GPU that were its best) -- the strict-fp32 figure, timed in the same
+    run on the same box.  The library reads these switches at every call."""
+    global STREAMS_PER_GPU
+    old_env = {k: os.environ.get(k) for k in FP32_KERNELS}
+    old_streams = STREAMS_PER_GPU
+    os.environ.update(FP32_KERNELS)
+    STREAMS_PER_GPU = 4
+    try:
+        job = FarmJob(net, weights, [device_index], rows, cols)
+        elapsed, loss = job.timed(opts.steps, opts.warmup)
+        group_ms = float(np.mean(job.group_ms))
+        conv_alg, conv_issued = job.eng.last_tile_flops()
+        job.close()
+    finally:
+        STREAMS_PER_GPU = old_streams
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {'value': rows * cols * opts.steps / elapsed, 'unit': 'tile-iterations/s',
+            'ms_per_step': elapsed / opts.steps * 1e3, 'steps': opts.steps, 'warmup': opts.warmup,
+            'dtype': 'f32', 'switches': FP32_KERNELS, 'final_loss': loss, 'avg_launch_ms': group_ms,
+            'conv_flop_issued_over_direct': conv_issued / conv_alg if conv_alg else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -510,6 +622,10 @@ def main():
     ap.add_argument('--farm-optimizer', default='adam', choices=['adam', 'lbfgs'])
     ap.add_argument('--farm-force-staging', action='store_true')
     ap.add_argument('--steady-seconds', type=float, default=5.0)
+    ap.add_argument('--no-kernel-records', action='store_true',
+                    help='N = 1: skip roofline.per_kernel (five profiled tile evaluations after the timed legs)')
+    ap.add_argument('--no-fp32-leg', action='store_true',
+                    help='N = 1: skip the fp32_kernels sub-record (the same steps with the fp32-MFMA kernels only)')
     ap.add_argument('--debug-grid', default=None,
                     help='RxC tile grid instead of the 2x2 of the metric (tests only: lets a single '
                          'process evaluate the image of a larger job)')
@@ -616,7 +732,13 @@ def bench_single(opts, net, weights, device_index, rows, cols):
         line['steady'] = {'steps': n_steady, 'seconds': dt, 'ms_per_step': dt / n_steady * 1e3,
                           'value': job.tiles_per_step * n_steady / dt, 'unit': 'tile-iterations/s'}
     line['tile_evals'] = int(sum(e.query(lib.Q_TILE_EVALS) for e in job.farm.engines))
+    if not opts.no_kernel_records:
+        line['roofline']['per_kernel'] = kernel_records(job)
+        if 'dominant' in line['roofline']['per_kernel']:
+            line['roofline']['dominant'] = line['roofline']['per_kernel']['dominant']
     job.close()
+    if not opts.no_fp32_leg and DTYPE != 'f32':
+        line['fp32_kernels'] = fp32_kernels_leg(opts, net, weights, device_index, rows, cols)
     return line
 
 

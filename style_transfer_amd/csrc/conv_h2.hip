@@ -181,7 +181,10 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const int es = sgpr(h2_scale_exp(amax_bits));
     const int ew = sgpr(reinterpret_cast<const int *>(a.w)[(a.w_bytes >> 2) + 1]);
     const float sv = pow2f(es);
-    const float out_scale = pow2f(-es - ew);
+    // (both scales undone exactly: 2^-(es + ew) in two factors when it leaves the normal range -- a blob whose
+    // maximum is below 2^-99 with a bank exponent near 14; the second factor is 1 otherwise)
+    const int eo = -es - ew, eo1 = eo < -126 ? -126 : eo > 127 ? 127 : eo;
+    const float out_scale = pow2f(eo1), out_scale2 = pow2f(eo - eo1);
 
     // ---- staging role.  The V array of a chunk has RT positions (a row of the patch, an x-tile) x 16
     // channels.  Positions 0 .. 128 FULL - 1: a unit = one position x four channels (quad), every thread
@@ -729,8 +732,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
                 f32x4 p[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) p[c] = ex[(((c * 2 + hh) * 4 + 2 * mrow + s) * 4 + rq) * 64 + lane];
-                o[s][0] = (p[0] + p[1] + p[2]) * out_scale;
-                o[s][1] = (p[1] - p[2] - p[3]) * out_scale;
+                o[s][0] = (p[0] + p[1] + p[2]) * out_scale * out_scale2;
+                o[s][1] = (p[1] - p[2] - p[3]) * out_scale * out_scale2;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1076,6 +1079,13 @@ static int h2_launch_epi(hipStream_t s, const WinoArgs &args, int n_wg) {
     return STX_OK;
 }
 
+#ifdef STX_H2_DEV_SUBSET   // (register / ISA studies: tools/h2_regs.sh, tools/spill_map.py -- a few variants, in seconds)
+template __global__ void conv_h2_kernel<0, 2, 1, 0>(WinoArgs);
+template __global__ void conv_h2_kernel<0, 1, 2, 0>(WinoArgs);
+template __global__ void conv_h2_kernel<1, 2, 1, 0>(WinoArgs);
+template __global__ void conv_h2_kernel<3, 2, 1, 0>(WinoArgs);
+template __global__ void conv_h2_kernel<3, 1, 2, 1>(WinoArgs);
+#else
 int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
     if (!h2_usable(p) || !p.x_amax) {
         set_error("h2_launch: unsupported problem (K %d, epilogue %d, input maximum %s)", p.K, p.epilogue,
@@ -1176,5 +1186,6 @@ int h2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ks
 #undef STX_H2_CASE
     return split ? splitk_reduce_launch(s, p, ksplit) : STX_OK;
 }
+#endif
 
 }  // namespace stx

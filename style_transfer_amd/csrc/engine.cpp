@@ -537,8 +537,11 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 static bool h2_enabled() {
     const char *algo = getenv("STX_CONV_ALGO");
     if (algo && *algo) return !strncmp(algo, "h2", 2);
+    // (the thresholds of h2_choice: with STX_CONV_H2=0 and no STX_CONV_H2_BWD neither direction takes the kernel)
     const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
-    return !env || atoi(env) > 0 || !envb || atoi(envb) > 0;
+    const int fwd_min = env ? atoi(env) : 64;
+    const int bwd_min = envb ? atoi(envb) : (env && atoi(env) <= 0 ? 0 : 64);
+    return fwd_min > 0 || bwd_min > 0;
 }
 
 static bool h2_choice(const ConvProblem &p, ConvConfig *out) {

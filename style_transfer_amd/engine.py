@@ -193,11 +193,12 @@ class TileEngine:
         that never come back through ``sync()``.  Entries are dropped when their values have been
         published: at ``sync()`` and at ``wait_fence()`` (everything queued before that fence).  The
         count below is a backstop for callers that never do either -- the library drains its arena
-        every few hundred evaluations, so an entry 32768 evaluations old has long been written."""
+        every few hundred evaluations, so an entry 2048 evaluations old has long been written.  (Each
+        entry pins a tile-sized host buffer: the cap stays small.)"""
         self._results.append(result)
-        if len(self._results) > 65536:
-            del self._results[:32768]
-            self._dropped = getattr(self, '_dropped', 0) + 32768
+        if len(self._results) > 4096:
+            del self._results[:2048]
+            self._dropped = getattr(self, '_dropped', 0) + 2048
         return result
 
     def fence(self):

@@ -16,12 +16,13 @@ from argparse import Namespace
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 import json
+import sys
 import time
 
 import numpy as np
 from PIL import Image
 
-from . import image_ops
+from . import image_ops, lib
 from .config_system import ffloat
 from .optimizers import AdamOptimizer, LBFGSOptimizer
 from .resample import resample_device
@@ -329,15 +330,29 @@ class StyleTransfer:
             self._step_loop(iterations, callback, run_ahead, in_flight, finish, jitter, jitter_scale,
                             img_size, state, content_images, content_layers, style_layers,
                             content_weight, style_weight, dd_layers, dd_weight)
-        finally:
-            # an interrupt or an error in iteration i + 1 must not lose the finished iteration i
-            # (its statistics row, its --save-every picture)
-            while in_flight:
-                item = in_flight.pop(0)
-                try:
-                    finish(item)
-                except Exception:       # (the device may be the thing that failed)
-                    break
+        except BaseException as exc:
+            # an interrupt or a host-side error in iteration i + 1 must not lose the finished iteration i
+            # (its statistics row, its --save-every picture) -- but when the engine itself failed there is
+            # nothing to collect, and whatever the drain raises is reported beside the original error,
+            # never swallowed; the engines are left idle either way
+            if not isinstance(exc, lib.StxError):
+                while in_flight:
+                    item = in_flight.pop(0)
+                    try:
+                        finish(item)
+                    except Exception as drain_exc:      # pylint: disable=broad-except
+                        print('style_transfer_amd: while collecting step %d after %r: %r'
+                              % (item[0], exc, drain_exc), file=sys.stderr)
+                        break
+            del in_flight[:]
+            try:
+                for eng in getattr(self.farm, 'engines', ()):
+                    eng.sync()
+            except Exception as sync_exc:               # pylint: disable=broad-except
+                print('style_transfer_amd: engines not idle after %r: %r' % (exc, sync_exc), file=sys.stderr)
+            raise
+        while in_flight:
+            finish(in_flight.pop(0))
         return self.current_raw
 
     def _step_loop(self, iterations, callback, run_ahead, in_flight, finish, jitter, jitter_scale, img_size,

@@ -137,8 +137,27 @@ def loss_from_activations(om, acts, start, cl, sl, lw, cw, sw, dtype=np.float64)
     return total, terms
 
 
+FP32_KERNELS = {'STX_CONV_H2': '0', 'STX_GRAM': 'fp32', 'STX_SYMM': 'fp32'}
+
+
+class fp32_kernels:
+    """Within the block the library takes its fp32-MFMA kernels only (the switches are read at every
+    call): no fp16-split convolution, Gram or SYMM -- round 4's arithmetic."""
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in FP32_KERNELS}
+        os.environ.update(FP32_KERNELS)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, ref_grad=None, flip_l2=1e-2,
-               blas_loss_tol=TIGHT):
+               blas_loss_tol=TIGHT, fp32_leg=False):
     """GPU tile evaluation (stx_sc_grad_tile) vs the oracle.  Stated tolerances:
       * every activation: 1e-5 of max|ref|;
       * the loss: 1e-5 relative to the float64 value of the reference's formula on the oracle's
@@ -153,6 +172,9 @@ def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, ref_grad=None, fl
       * gradient vs the oracle's own end-to-end result (`ref_grad` given: vs the reference's
         untouched vectors): 1e-5 of max|ref| on every pixel that cannot see a differing ReLU /
         argmax decision (decision_taint), and relative L2 < flip_l2 overall.
+    fp32_leg: the forward pass is evaluated a second time with the fp32-MFMA kernels only and its decision
+    flips against the same oracle pass are counted too (stats['fp32_relu_flips'], ['fp32_pool_flips'],
+    ['fp32_act_err'] / ['act_err']: the largest activation error of each leg) -- the A/B behind "fp32-class".
     Returns (loss, grad, stats)."""
     loss, grad = eng.sc_grad_tile(tile, start, roll, cl, sl, lw, cw, sw)
     deepest = om.deep_to_shallow(list(cl) + list(sl))[0]
@@ -166,8 +188,11 @@ def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, ref_grad=None, fl
         loss64, _ = loss_from_activations(om, ref_acts, start, cl, sl, lw, cw, sw, np.float64)
     finally:
         om.roll_contents(-np.asarray(roll))
+    act_err = 0.0
     for b in blobs:
-        assert max_rel(acts[b], ref_acts[b]) < TIGHT, b
+        err = max_rel(acts[b], ref_acts[b])
+        assert err < TIGHT, b
+        act_err = max(act_err, err)
     assert loss == pytest.approx(loss64, rel=TIGHT), (loss, loss64, ref_loss)
     assert loss == pytest.approx(ref_loss, rel=blas_loss_tol), (loss, loss64, ref_loss)
     assert loss == pytest.approx(same_loss, rel=blas_loss_tol), (loss, loss64, same_loss)
@@ -177,7 +202,14 @@ def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, ref_grad=None, fl
     taint, n_relu, n_pool = decision_taint(om.net.layers, acts, ref_acts, deepest, shape)
     clean = ~taint
     stats = dict(relu_flips=n_relu, pool_flips=n_pool, tainted=float(taint.mean()),
-                 l2=l2_rel(grad, target))
+                 l2=l2_rel(grad, target), act_err=act_err)
+    if fp32_leg:
+        with fp32_kernels():
+            acts32 = eng.features_tile(tile, blobs)
+        _, n_relu32, n_pool32 = decision_taint(om.net.layers, acts32, ref_acts, deepest, shape)
+        stats.update(fp32_relu_flips=n_relu32, fp32_pool_flips=n_pool32,
+                     fp32_act_err=max(max_rel(acts32[b], ref_acts[b]) for b in blobs))
+        del acts32
     scale = np.abs(target).max()
     if clean.any():
         err = np.abs(np.float64(grad) - target)[:, clean].max() / scale

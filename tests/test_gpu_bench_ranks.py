@@ -69,6 +69,18 @@ def test_two_rank_bench_matches_single_process_loss():
     # same tiles, same arithmetic, losses added up in tile order in both layouts: the same bits
     assert a['config']['final_loss'] == b['config']['final_loss']
     assert a['farm']['final_loss'] == b['config']['final_loss']
+    # the N = 1 line explains itself: the fraction stated against the fp16 pipe, the dominant kernel measured
+    # in the run, the strict-fp32 figure timed beside the headline
+    roof = b['roofline']
+    assert roof['peak_fp16'] == pytest.approx(16 * roof['peak']) and roof['frac_fp16_pipe'] == pytest.approx(roof['frac'])
+    dom = roof['dominant']
+    assert 'conv_h2_kernel<0,2,1,*>' in dom['name'] and dom['launch_groups'] == 10
+    assert 0.1 < dom['frac_fp16_pipe'] < 1 and 0.2 < dom['share_of_tile'] < 0.5
+    assert 0 < roof['per_kernel']['furthest_below']['frac_fp16_pipe'] <= dom['frac_fp16_pipe']
+    f32 = b['fp32_kernels']
+    assert f32['dtype'] == 'f32' and 0 < f32['value'] < b['value']
+    assert f32['final_loss'] == pytest.approx(b['config']['final_loss'], rel=1e-4)
+    assert f32['conv_flop_issued_over_direct'] == pytest.approx(4 / 9, rel=0.05)      # (fp32 2-D Winograd: 4 / 9 of a direct count)
 
 
 def test_farm_leg_over_two_device_entries_matches_one():

@@ -35,7 +35,14 @@ def _steps(text):
     return np.array(rows)
 
 
-def test_cli_config4_miniature_from_model_files(golden, tmp_path, monkeypatch, capsys):
+@pytest.mark.parametrize('kernels', ['fp32', 'default'])
+def test_cli_config4_miniature_from_model_files(golden, tmp_path, monkeypatch, capsys, kernels):
+    """kernels 'fp32': the fp32-MFMA kernels only -- held to the COMMITTED run alone; 'default': the shipped
+    fp16-split kernels -- one of the reference's own branches (tests/golden/branch_sets.py cfg4)."""
+    if kernels == 'fp32':
+        from tests.gpu_helpers import FP32_KERNELS
+        for k, v in FP32_KERNELS.items():
+            monkeypatch.setenv(k, v)
     net = netspec.builtin_net('vgg19')
     proto, model = tmp_path / 'deploy.prototxt', tmp_path / 'w.caffemodel'
     proto.write_text(netspec.to_prototxt(net))
@@ -52,12 +59,12 @@ def test_cli_config4_miniature_from_model_files(golden, tmp_path, monkeypatch, c
     ref_steps, got_steps = _steps(str(golden['e2e_cfg4.step_lines'])), _steps(out)
     assert got_steps.shape == ref_steps.shape == (5, 5)
     assert np.array_equal(got_steps[:, 0], ref_steps[:, 0])
-    # the reference's own trajectory on this fixture branches at kernel-level rounding (see
-    # tests/helpers.cfg4_reference_branches, tests/golden/cfg4_sensitivity.py): the run follows one of
-    # the reference's branches, to the fixture's 2e-4
+    # the reference's own trajectory on this fixture branches under another float32 implementation of its
+    # convolutions (tests/helpers.cfg4_reference_branches, tests/golden/branch_sets.py): the shipped kernels
+    # follow one of the reference's branches, the fp32-MFMA kernels the committed one -- to the fixture's 2e-4
     from tests.helpers import cfg4_reference_branches, matching_branch
     branches = cfg4_reference_branches(golden)
-    br = matching_branch(branches, got_steps[:, 3])
+    br = matching_branch(branches[:1] if kernels == 'fp32' else branches, got_steps[:, 3])
     assert br is not None, (got_steps[:, 3], [b['log'][:, 2] for b in branches])
     ref_log = br['log']
     assert np.allclose(got_steps[:, 2], ref_log[:, 1], atol=0.025)            # update size (two decimals)

@@ -156,94 +156,133 @@ def test_device_preprocessing_equals_host_stitching():
     farm.close()
 
 
-def test_lbfgs_avgpool_two_styles_matches_reference_run(golden):
-    """BASELINE configs 4 / 5 in miniature: -o lbfgs, vgg16_avgpool, two style images (Grams
-    averaged), 2 scales, 2x2 tiles -- against the reference's own transfer_multiscale run."""
+def _run_fixture(golden, key, style_keys, kernels):
+    """One multi-scale run of an end-to-end fixture on the GPU; kernels 'fp32': with the fp32-MFMA
+    kernels only (gpu_helpers.fp32_kernels).  Returns (log [steps][4], final raw image, tile evaluations)."""
+    import contextlib
     from argparse import Namespace
-    argv = str(golden['e2e_lbfgs.argv']).split()
+    from tests.gpu_helpers import fp32_kernels
+    argv = str(golden[key + '.argv']).split()
     state = Namespace()
     args = parse_args(state, argv, config_py=False)
     net = builtin_net(args.model)
-    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
-    st = StyleTransfer(farm, args, state)
-    log = []
-    np.random.seed(args.seed)
-    st.transfer_multiscale([Image.fromarray(golden['e2e_lbfgs.content_u8'])],
-                           [Image.fromarray(golden['e2e_lbfgs.style0_u8']),
-                            Image.fromarray(golden['e2e_lbfgs.style1_u8'])],
-                           callback=lambda **kw: log.append(
-                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
-    # The reference's outcome on this fixture is DISCRETE under kernel-level rounding (tests/golden/
-    # lbfgs_sensitivity.py: its own code with its convolutions or Gram matrices moved by 3e-7 of their
-    # maximum lands on one of a set of final pictures, 0.5 .. 13 apart -- ReLU near-ties in a 40-pixel
-    # tile's deep layers, each moving one patch of the picture, amplified by five L-BFGS steps, in any
-    # combination: 11 distinct pictures in 25 runs; the losses of most agree to 1e-5).  A faithful float32
-    # implementation lands on one of them or on another combination of the same flips -- the fp32-MFMA
-    # Gram kernel reproduces one of the sampled pictures to 0.002, the bf16 three-piece kernels another to
-    # 0.5 -- so: the losses follow the nearest outcome's to the 2e-4 this test always had, and every pixel
-    # agrees with SOME outcome of the reference to the bounds it always had (max 2.0, mean 0.02).
+    with fp32_kernels() if kernels == 'fp32' else contextlib.nullcontext():
+        farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
+        st = StyleTransfer(farm, args, state)
+        log = []
+        np.random.seed(args.seed)
+        st.transfer_multiscale([Image.fromarray(golden[key + '.content_u8'])],
+                               [Image.fromarray(golden['%s.%s' % (key, k)]) for k in style_keys],
+                               callback=lambda **kw: log.append(
+                                   (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
+        raw = st.current_raw.get()
+        evals = farm.tile_evals
+        farm.close()
+    import os
+    if os.environ.get('STX_E2E_DUMP'):          # (for tests/golden/branch_sets.py's offline comparison)
+        np.savez_compressed(os.path.join(os.environ['STX_E2E_DUMP'], '%s_%s.npz' % (key, kernels)),
+                            log=np.float64(log), final_raw=raw)
+    return np.float64(log), raw, evals
+
+
+# The two chaotic L-BFGS fixtures run twice.  'fp32': with the fp32-MFMA kernels only (round 4's arithmetic:
+# STX_CONV_H2=0, fp32 Gram and SYMM) the run is held to the COMMITTED reference run alone, with the bounds the
+# tests had before the fp16-split kernels existed -- a regression anywhere else cannot hide inside a set of
+# outcomes.  'default': the shipped kernels must follow ONE outcome of the reference's own code under another
+# float32 implementation of its Convolution layer / Gram matrix (tests/golden/branch_sets.py), whole run and
+# whole picture against that single outcome.
+@pytest.mark.parametrize('kernels', ['fp32', 'default'])
+def test_lbfgs_avgpool_two_styles_matches_reference_run(golden, kernels):
+    """BASELINE configs 4 / 5 in miniature: -o lbfgs, vgg16_avgpool, two style images (Grams
+    averaged), 2 scales, 2x2 tiles -- against the reference's own transfer_multiscale run."""
+    got, raw, evals = _run_fixture(golden, 'e2e_lbfgs', ['style0_u8', 'style1_u8'], kernels)
+    # L-BFGS evaluates the objective once more at the start of every scale (optimizers.py:76-77)
+    assert evals == 4 * (3 + 1) + 4 * (2 + 1)
+    if kernels == 'fp32':
+        ref = golden['e2e_lbfgs.log']
+        assert got.shape == ref.shape
+        assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
+        assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
+        diff = np.abs(raw - golden['e2e_lbfgs.final_raw'])
+        print('fp32 kernels against the committed picture: max %.4f mean %.6f' % (diff.max(), diff.mean()))
+        assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
+        return
+    # The shipped kernels, against the committed run ALONE.  What the reference's own code does on this fixture
+    # with another float32 implementation of its Convolution layer or its Gram matrix (tests/golden/
+    # branch_sets.py lbfgs: 14 + 6 real implementations, 12 runs with noise of the amplitude those measure --
+    # tests/golden/lbfgs_runs.json, one picture per distinct outcome in lbfgs_branches.npz): the losses stay
+    # within 8.2e-4 (30 of 33 runs within 1e-5), 30 runs reproduce the committed picture to 0.001, the other
+    # three move ONE patch of it -- a ReLU near-tie of a 40-pixel tile's deep layers decided the other way,
+    # amplified by five L-BFGS steps -- by 0.59 (3 values beyond 0.5), 1.82 (71) and 7.03 (779; mean 0.12).
+    # So: the losses to the fixture's 2e-4, the mean to the bound it always had, and the displaced patch
+    # bounded in height AND in area by what the reference does to itself -- instead of round 5's per-pixel
+    # minimum over a set of outcomes (a patchwork of outcomes passed that).
     from tests.helpers import lbfgs_reference_outcomes
-    got, raw = np.float64(log), st.current_raw.get()
     outcomes = lbfgs_reference_outcomes(golden)
-    assert got.shape == outcomes[0]['log'].shape
-    dist = [float(np.abs(raw - o['final_raw']).max()) for o in outcomes]
-    print('final image against the reference\'s outcomes: max |diff|', np.round(dist, 3))
-    br = outcomes[int(np.argmin(dist))]
-    ref = br['log']
+    ref = golden['e2e_lbfgs.log']
+    assert got.shape == ref.shape
     assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
     assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
-    diff = np.min([np.abs(raw - o['final_raw']) for o in outcomes], axis=0)
-    print('  per-pixel distance to the nearest of the outcomes: max %.4f mean %.6f; to the nearest single one %.4f'
-          % (diff.max(), diff.mean(), min(dist)))
-    assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
-    # (... and against the committed picture alone the mean bound still holds: the flips are few)
-    assert np.abs(raw - golden['e2e_lbfgs.final_raw']).mean() < 0.02
-    # L-BFGS evaluates the objective once more at the start of every scale (optimizers.py:76-77)
-    assert farm.tile_evals == 4 * (3 + 1) + 4 * (2 + 1)
-    farm.close()
+    diff = np.abs(raw - golden['e2e_lbfgs.final_raw'])
+    own = [np.abs(o['final_raw'] - golden['e2e_lbfgs.final_raw']) for o in outcomes[1:]]
+    print('against the committed picture: max %.4f mean %.6f, %d values beyond 0.5 (the reference against itself: %s)'
+          % (diff.max(), diff.mean(), (diff > 0.5).sum(),
+             ', '.join('%.2f / %d' % (d.max(), (d > 0.5).sum()) for d in own)))
+    assert diff.mean() < 0.02, (diff.max(), diff.mean())
+    assert diff.max() <= max(d.max() for d in own) + 0.5, diff.max()
+    assert (diff > 0.5).sum() <= 0.005 * diff.size, int((diff > 0.5).sum())       # one patch: 0.5 % of the picture
 
 
-def test_config4_miniature_matches_reference_run(golden):
+@pytest.mark.parametrize('kernels', ['fp32', 'default'])
+def test_config4_miniature_matches_reference_run(golden, kernels):
     """BASELINE config 4's own combination -- VGG-19 (MAX pooling) x L-BFGS x a 3 x 3 tiling whose
     last row and column are larger (style_transfer.py:619-632) -- against the reference's run
     (tests/golden/make_golden.py section 4c): 65 x 71 with 2 x 2 tiles, then 92 x 100 with tiles
     of 30/30/32 x 33/33/34."""
-    from argparse import Namespace
-    argv = str(golden['e2e_cfg4.argv']).split()
-    state = Namespace()
-    args = parse_args(state, argv, config_py=False)
-    net = builtin_net(args.model)
-    farm = TileFarm(net, [0], synthetic_weights(net, 0), verbose=False)
-    st = StyleTransfer(farm, args, state)
-    log = []
-    np.random.seed(args.seed)
-    st.transfer_multiscale([Image.fromarray(golden['e2e_cfg4.content_u8'])],
-                           [Image.fromarray(golden['e2e_cfg4.style_u8'])],
-                           callback=lambda **kw: log.append(
-                               (kw['step'], kw['update_size'], kw['loss'], kw['tv_loss'])))
-    # The reference's trajectory on this fixture BRANCHES when its convolutions are rounded as any other
-    # float32 kernel rounds them (tests/golden/cfg4_sensitivity.py: half of the reference's own runs leave
-    # the committed log by 5.6e-4 at the second step -- tiles of 30 x 33 pixels, one near-tie moves the
-    # objective by 1e-3): the run must follow ONE of the reference's branches, to the fixture's 2e-4.
+    got, raw, evals = _run_fixture(golden, 'e2e_cfg4', ['style_u8'], kernels)
+    # 4 tiles x (3 + 1) evaluations at the first scale, 9 tiles x (2 + 1) at the second
+    assert evals == 4 * (3 + 1) + 9 * (2 + 1)
     from tests.helpers import cfg4_reference_branches, matching_branch
-    got = np.float64(log)
     branches = cfg4_reference_branches(golden)
     print([np.array2string(got[:, 2] / b['log'][:, 2] - 1, precision=2) for b in branches])
     assert got.shape == branches[0]['log'].shape
-    br = matching_branch(branches, got[:, 2])
+    # fp32 kernels: the committed trajectory and no other.  Default kernels: the reference's trajectory on this
+    # fixture BRANCHES under another float32 implementation of its convolutions (tests/golden/branch_sets.py
+    # cfg4: tiles of 30 x 33 pixels, one near-tie moves the objective by 1e-3) -- ONE of its branches, to 2e-4.
+    br = matching_branch(branches[:1] if kernels == 'fp32' else branches, got[:, 2])
     assert br is not None, (got[:, 2], [b['log'][:, 2] for b in branches])
     ref = br['log']
     assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
     assert np.allclose(got[:, 3], ref[:, 3], rtol=2e-3)
     # (the last line search flips on its own: the unperturbed reference repeated differs from itself by
     # 0.06 .. 0.9 in the final picture)
-    diff = np.abs(st.current_raw.get() - br['final_raw'])
+    diff = np.abs(raw - br['final_raw'])
     print('final image: max %.4f mean %.6f (branch taken by %d of the reference\'s runs)'
           % (diff.max(), diff.mean(), br['runs']))
     assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
-    # 4 tiles x (3 + 1) evaluations at the first scale, 9 tiles x (2 + 1) at the second
-    assert farm.tile_evals == 4 * (3 + 1) + 9 * (2 + 1)
-    farm.close()
+
+
+def test_lbfgs_multi_tile_run_at_a_stable_size_matches_reference_run(golden):
+    """The L-BFGS pin at a size where ONE reference trajectory exists (make_golden.py
+    section 4j): VGG-19 with AVE pooling x L-BFGS x a ragged 2 x 2 tiling of 97 .. 140-pixel tiles, 3 + 2
+    iterations.  tests/golden/branch_sets.py stable: under every other float32 implementation of the
+    reference's Convolution layer tried (14) and calibrated noise (8 runs) its losses stay within 4e-5 of
+    the committed run at every step -- so the shipped kernels are held to that one trajectory at the plain
+    2e-4.  (With MAX pooling the reference leaves the band at ANY size: the 280-pixel VGG-19 run moves by
+    2e-4 at step 2 and 2.4e-3 at step 5 between its own SGEMM and torch's conv2d.)  The final picture still
+    carries the ReLU near-ties of five steps as displaced patches (the reference against itself: max 9 .. 20,
+    mean 0.01 .. 0.07): bounded in the mean."""
+    got, raw, evals = _run_fixture(golden, 'e2e_stable', ['style_u8'], 'default')
+    assert evals == 4 * (3 + 1) + 4 * (2 + 1)
+    ref = golden['e2e_stable.log']
+    assert got.shape == ref.shape
+    print('stable fixture: loss against the committed run', np.array2string(got[:, 2] / ref[:, 2] - 1, precision=2))
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=2e-4), (got[:, 2], ref[:, 2])
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=2e-3)
+    assert np.allclose(got[:, 3], ref[:, 3], rtol=2e-3)
+    diff = np.abs(raw - golden['e2e_stable.final_raw'])
+    print('  final picture: max %.3f mean %.5f' % (diff.max(), diff.mean()))
+    assert diff.mean() < 0.15, (diff.max(), diff.mean())
 
 
 def test_farm_staged_leg_equals_direct_leg():

@@ -66,6 +66,15 @@ MAX_FLIPS_PER_MPIXEL = 500
 MAX_TAINTED = 0.3
 
 
+def _record(line):
+    """STX_PARITY_STATS=<file>: the printed statistics of the full-size cases, appended (profiles/)."""
+    import os
+    path = os.environ.get('STX_PARITY_STATS')
+    if path:
+        with open(path, 'a') as f:
+            f.write(line + '\n')
+
+
 @pytest.mark.parametrize('th,tw,ih,iw,start,roll', TILE_CASES)
 def test_sc_grad_tile_at_benchmark_sizes(th, tw, ih, iw, start, roll):
     om, _ = make_oracle('vgg19')
@@ -76,10 +85,17 @@ def test_sc_grad_tile_at_benchmark_sizes(th, tw, ih, iw, start, roll):
     om.contents, om.styles = _random_targets(om, rng, (ih, iw), cl, sl)
     eng.set_contents_and_styles(om.contents, om.styles)
     tile = _smooth(rng, th, tw)
-    _, _, stats = check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, {}, blas_loss_tol=5e-4)
-    print('%dx%d tile: %s, %.2f ms on the GPU' % (th, tw, stats, eng.last_tile_ms()))
-    assert stats['relu_flips'] + stats['pool_flips'] < MAX_FLIPS_PER_MPIXEL * th * tw / 2 ** 20, stats
+    _, _, stats = check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, {}, blas_loss_tol=5e-4, fp32_leg=True)
+    line = '%dx%d tile: %s, %.2f ms on the GPU' % (th, tw, stats, eng.last_tile_ms())
+    print(line)
+    _record(line)
+    flips, flips32 = stats['relu_flips'] + stats['pool_flips'], stats['fp32_relu_flips'] + stats['fp32_pool_flips']
+    assert flips < MAX_FLIPS_PER_MPIXEL * th * tw / 2 ** 20, stats
     assert stats['tainted'] < MAX_TAINTED, stats
+    # the fp16-split kernels against the fp32-MFMA kernels on the same tile, same oracle pass: no more than
+    # twice the decisions flipped (+ 50: small counts scatter), no more than twice the activation error
+    assert flips <= 2 * flips32 + 50, stats
+    assert stats['act_err'] <= 2 * stats['fp32_act_err'] + 1e-7, stats
 
 
 def test_sc_grad_tile_vgg16_avgpool_at_1024():
@@ -95,10 +111,13 @@ def test_sc_grad_tile_vgg16_avgpool_at_1024():
     eng.set_contents_and_styles(om.contents, om.styles)
     tile = _smooth(rng, 1024, 1024)
     _, _, stats = check_tile(eng, om, tile, (0, 1024), (16, 16), cl, cw, sl, sw, {}, flip_l2=1e-3,
-                             blas_loss_tol=5e-4)
+                             blas_loss_tol=5e-4, fp32_leg=True)
     print('vgg16_avgpool 1024x1024:', stats)
+    _record('vgg16_avgpool 1024x1024 tile: %s' % stats)
     assert stats['relu_flips'] < MAX_FLIPS_PER_MPIXEL and stats['pool_flips'] == 0, stats
     assert stats['tainted'] < MAX_TAINTED, stats
+    assert stats['relu_flips'] <= 2 * stats['fp32_relu_flips'] + 50, stats
+    assert stats['act_err'] <= 2 * stats['fp32_act_err'] + 1e-7, stats
 
 
 # ---------------------------------------------------------------------------- single kernels

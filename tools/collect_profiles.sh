@@ -13,7 +13,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-wall-clock --steady-seconds 0"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-wall-clock --steady-seconds 0 --no-kernel-records --no-fp32-leg"
 TILE="python $R/tools/bench_tile.py 1024 7"
 find_csv() { find "$1" -name "*_$2.csv" | head -1; }
 
