@@ -580,11 +580,13 @@ FP32_KERNELS = {'STX_CONV_H2': '0', 'STX_GRAM': 'fp32', 'STX_SYMM': 'fp32', 'STX
 def fp32_kernels_leg(opts, net, weights, device_index, rows, cols):
     """The same step loop with the fp32-MFMA kernels only (no fp16-split convolution, Gram or SYMM: round 4's
     arithmetic, on the four streams per GPU that were its best) -- the strict-fp32 figure, timed in the same
-    run on the same box.  The library reads these switches at every call."""
+    run on the same box (stx_reread_env: the library takes a new snapshot of its switches)."""
     global STREAMS_PER_GPU
     old_env = {k: os.environ.get(k) for k in FP32_KERNELS}
     old_streams = STREAMS_PER_GPU
+    from style_transfer_amd import lib
     os.environ.update(FP32_KERNELS)
+    lib.reread_env()
     STREAMS_PER_GPU = 4
     try:
         job = FarmJob(net, weights, [device_index], rows, cols)
@@ -599,6 +601,7 @@ def fp32_kernels_leg(opts, net, weights, device_index, rows, cols):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        lib.reread_env()
     return {'value': rows * cols * opts.steps / elapsed, 'unit': 'tile-iterations/s',
             'ms_per_step': elapsed / opts.steps * 1e3, 'steps': opts.steps, 'warmup': opts.warmup,
             'dtype': 'f32', 'switches': FP32_KERNELS, 'final_loss': loss, 'avg_launch_ms': group_ms,

@@ -68,6 +68,11 @@ typedef struct stx_layer_desc {
 const char *stx_version(void);
 /* Message of the calling thread's most recent failing call ("" if none). */
 const char *stx_last_error(void);
+/* The library's STX_* switches (A/B levers, test hooks) are read from a snapshot of
+ * the environment taken at first use, not with getenv() at every launch; a program that changes one while it
+ * runs calls this to take a new snapshot.  (No counterpart in the reference: its only run-time switches are the
+ * command line's, config_system.py:26-118.) */
+int stx_reread_env(void);
 /* Number of visible GPUs; replaces detect_devices() (config_system.py:17-24, nvidia-smi -L). */
 int stx_device_count(int *count);
 /* gcnArchName of a device (e.g. "gfx950:sramecc+:xnack-") into buf. */

@@ -20,9 +20,7 @@ ARCH = 'gfx950'
 
 SOURCES = {
     'conv_mfma.hip': [],
-    'conv_wino.hip': [],
     'conv_wino2.hip': [],
-    'conv_wino4.hip': [],
     'conv_first.hip': [],
     'conv_h2.hip': [],
     'gram.hip': [],

@@ -18,6 +18,15 @@ constexpr float kEps = 1.1920928955078125e-07f;
 
 void set_error(const char *fmt, ...);
 
+// The library's STX_* switches (A/B levers and test hooks: INTEGRATION.md lists them).  They are read from a
+// SNAPSHOT of the process environment -- taken when the library is first asked for one and again at every
+// stx_reread_env() -- never with getenv() at a call site: the launch paths run on several host threads (one per
+// engine of a farm), and getenv() beside a setenv() of the host program is a data race.  A caller that changes a
+// switch inside a process (the tests do, bench.py's fp32 leg does) calls stx_reread_env() afterwards.  Returns
+// the value or null, like getenv(); the pointer stays valid for the life of the process.
+const char *sw_env(const char *name);
+void sw_reread();
+
 #define STX_HIP(call)                                                                       \
     do {                                                                                    \
         hipError_t err__ = (call);                                                          \
@@ -231,10 +240,8 @@ struct WinoArgs {
 #endif
 };
 
-// 1-D Winograd F(2,3) variant of the 3x3 convolution (conv_wino.hip); configs have id >= 100.
-// wino_config_by_id(0..2) are its variants, wino_config_by_id(100) is the 2-D kernel below; the
-// other three functions dispatch on cfg.id.
-ConvConfig wino_config_by_id(int id);
+// The Winograd configurations (cfg.id 200-202: conv_wino2.hip, fp32 2-D F(2x2,3x3); 300-302: conv_h2.hip,
+// fp16-split 1-D F(2,3)): these three dispatch on cfg.id (conv_wino2.hip).
 size_t wino_packed_floats(const ConvConfig &cfg, int K, int M);
 int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
                       const ConvConfig &cfg, float *packed);
@@ -285,13 +292,6 @@ bool h2_fuses_pool(const ConvProblem &p);
 bool h2_takes_pooled_input(const ConvConfig &cfg, const ConvProblem &p);   // ConvProblem::pin_codes
 // slots[0 .. kAmaxSlots) = 0, then max |x| as float bits into them (the largest slot counts)
 int absmax_launch(hipStream_t s, const float *x, size_t n, unsigned *slots);
-
-// Four-wave form of the same kernel (conv_wino4.hip); config ids 210 (4 x 64 pixel patches),
-// 211 (16 x 16), 212 (8 x 32).  Shares the packed bank, the pooling rule and the K-split model.
-ConvConfig wino4_config(int geometry = 0);
-int wino4_pick_geometry(int K, int M, int H, int W);
-double wino4_geometry_cost(int geometry, int K, int M, int H, int W);   // model microseconds
-int wino4_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit);
 
 // 3x3 convolution with <= 4 output channels (backward into the image) on the 4x4x1 MFMA.
 size_t conv_small_packed_floats(int K);

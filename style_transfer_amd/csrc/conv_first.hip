@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kNT, GRAM ? 2 : 3) void conv_first_kernel(FirstArgs
 
 // The shapes this kernel takes: a 3 x 3 layer from at most three planes into exactly 64 channels.
 bool conv_first_usable(int K, int M, int ksize) {
-    const char *env = getenv("STX_CONV_FIRST_FUSED");
+    const char *env = sw_env("STX_CONV_FIRST_FUSED");
     if (env && atoi(env) == 0) return false;
     return ksize == 3 && K >= 1 && K <= 3 && M == kFM;
 }
@@ -356,7 +356,7 @@ int conv_first_workgroups(int H, int W) {
 // (without the Gram tile's 48 accumulator registers three workgroups fit a CU)
 static int conv_first_plain_workgroups(int H, int W) {
     const long tiles = (long)H * ceil_div(W, kFP);
-    const char *env = getenv("STX_FIRST_WGS");
+    const char *env = sw_env("STX_FIRST_WGS");
     return (int)std::min<long>(tiles, env ? atoi(env) : 768);
 }
 
@@ -384,7 +384,7 @@ int conv_first_launch(hipStream_t s, const float *x, const float *w_caffe, const
     a.vec_store = W % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     const int grid = gram_partials ? conv_first_workgroups(H, W) : conv_first_plain_workgroups(H, W);
     {
-        const char *env = getenv("STX_FIRST_STRIDED");
+        const char *env = sw_env("STX_FIRST_STRIDED");
         a.strided = env && atoi(env) != 0;
     }
     const int store = 4.0 * kFM * (double)H * W >= 4294967280.0 ? 2 : a.vec_store ? 0 : 1;

@@ -371,7 +371,7 @@ int conv_num_workgroups(const ConvConfig &cfg, int M, int H, int W) {
 
 ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
     if (ksize == 1) {
-        const char *force = getenv("STX_CONV_SYMM");                       // tuning aid: 6, 7, 12-14
+        const char *force = sw_env("STX_CONV_SYMM");                       // tuning aid: 6, 7, 12-14
         if (force && *force) return make_config(atoi(force));
         // small planes: many small workgroups (measured: 64x64 px x 512 ch 0.086 -> 0.033 ms,
         // 128x128 0.087 -> 0.076; larger planes are faster with the big tiles)
@@ -379,11 +379,11 @@ ConvConfig conv_pick_config(int ksize, int K, int M, int H, int W) {
         return make_config(M >= 128 ? 6 : 7);
     }
     if (K <= 4) {
-        const char *first = getenv("STX_CONV_FIRST");
+        const char *first = sw_env("STX_CONV_FIRST");
         return make_config(first ? atoi(first) : 8);
     }
     if (M <= 32) return make_config(3);
-    if (const char *force = getenv("STX_CONV_FORCE")) {   // tuning aid: force one tile config
+    if (const char *force = sw_env("STX_CONV_FORCE")) {   // tuning aid: force one tile config
         const int id = atoi(force);
         if (id >= 0 && id <= 11 && id != 3 && id != 4 && id != 6 && id != 7 && id != 8)
             return make_config(id);
@@ -776,7 +776,7 @@ int splitk_reduce_launch(hipStream_t s, const ConvProblem &p, int ksplit) {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(r.part) | reinterpret_cast<uintptr_t>(r.y) |
                            reinterpret_cast<uintptr_t>(r.mask) | reinterpret_cast<uintptr_t>(r.inj.feat) |
                            reinterpret_cast<uintptr_t>(r.inj.sgrad);
-    const char *env = getenv("STX_REDUCE_VEC");
+    const char *env = sw_env("STX_REDUCE_VEC");
     if ((p.H * p.W) % 4 == 0 && (ptrs & 15) == 0 && n < (1u << 31) && !(env && atoi(env) == 0)) {
         const size_t n4 = n / 4;
         splitk_reduce_vec4_kernel<<<(int)std::min<size_t>((n4 + 255) / 256, p.y_amax ? 1024 : 4096), 256, 0, s>>>(r);
@@ -1031,7 +1031,7 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
         return STX_ERR_ARG;
     }
     const double xb = 4.0 * K * (double)H * W;
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     const bool big = xb >= 2147483648.0 || (force_big && atoi(force_big) == 1);
     if (4.0 * kSmallKC * (double)H * W >= 2147483648.0) {
         set_error("conv_small_launch: a %d x %d plane is beyond the buffer-addressing limit", H, W);
@@ -1051,14 +1051,14 @@ int conv_small_launch(hipStream_t s, const float *x, const float *packed, float 
     a.x_bytes = big ? 0 : (int)xb;
     a.w_bytes = (int)(conv_small_packed_floats(K) * 4);
     // 16-byte loads need 16-byte aligned rows: plane width a multiple of 4, aligned base
-    const char *novec = getenv("STX_SMALL_NOVEC");
+    const char *novec = sw_env("STX_SMALL_NOVEC");
     const bool vec = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !(novec && atoi(novec));
     // 16-row patches (10 % of halo rows, 0.75 LDS reads per MFMA) where the plane still yields a
     // few workgroups per CU; 8-row patches (25 %, 1.2) on small planes
     const bool tall = (long)a.tiles_x * ceil_div(H, kSmallPR) >= 1024;
     int pr = tall ? kSmallPR : kSmallPR / 2;
 #ifdef STX_SMALL_SWEEP      // tuning aid (tools/bench_small.py): STX_SMALL_TUNE=<KC><PR code>, identical results
-    if (const char *tune = getenv("STX_SMALL_TUNE")) {
+    if (const char *tune = sw_env("STX_SMALL_TUNE")) {
         const int kc = atoi(tune) / 100, prr = atoi(tune) % 100;
         a.n_chunks = ceil_div(K, kc);
         a.n_wg = a.tiles_x * ceil_div(H, prr);

@@ -1,6 +1,6 @@
 // 3x3 convolution through 2-D Winograd F(2x2, 3x3) on the fp32 matrix cores.
 //
-// Same job and interface as conv_mfma_kernel / conv_wino_kernel (forward + bias + ReLU,
+// Same job and interface as conv_mfma_kernel (forward + bias + ReLU,
 // backward-to-data + ReLU mask + loss-gradient terms, split-K partials) with 16 multiplies per
 // 2x2 output tile and input channel instead of 36 (Lavin & Gray):
 //     V = Bt d B   (d = 4x4 input patch at rows 2ty-1.., columns 2tx-1..)
@@ -832,7 +832,7 @@ int wino2_pick_geometry(int H, int W) {
     // planes of a 724-pixel tile: 36 instead of 46 per channel tile) -- the third geometry the
     // four-wave kernel has had since round 2, now also for the layers only this kernel runs (the
     // loss-injecting ones).  STX_WINO2_GEO8X32=0 keeps the two-geometry rule.
-    const char *env = getenv("STX_WINO2_GEO8X32");
+    const char *env = sw_env("STX_WINO2_GEO8X32");
     if (env && atoi(env) == 0) return 0;
     const long wide = (long)ceil_div(H, Geo<32>::PR) * ceil_div(W, Geo<32>::PC);
     const long mid = (long)ceil_div(H, Geo<16>::PR) * ceil_div(W, Geo<16>::PC);
@@ -853,7 +853,7 @@ static Wino2Tail wino2_tail_plan(const ConvConfig &cfg, const ConvProblem &p, do
     if (p.epilogue != kEpiForward && p.epilogue != kEpiDgrad) return none;
     // the fused pooling and the ReLU nibbles belong to the unsplit epilogue
     if (!any_epilogue && (p.pool_out || p.wants_codes || p.in_codes || p.mask_codes)) return none;
-    const char *env = getenv("STX_WINO2_TAIL");      // (=0: off; read at every call)
+    const char *env = sw_env("STX_WINO2_TAIL");      // (=0: off)
     if (env && atoi(env) == 0) return none;
     const int n_chunks = ceil_div(p.K, KC);
     const long n = (long)ceil_div(p.M, BM) * ceil_div(p.H, cfg.pr) * ceil_div(p.W, cfg.pc);
@@ -972,14 +972,14 @@ int wino2_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int 
 }
 
 // The eight-wave kernel writes / reads ReLU sign nibbles unless the launch is sliced along K.
-// STX_RELU_CODES=0 (read at every call) keeps the fp32 masks, for A/B measurements and tests.
+// STX_RELU_CODES=0 (stx_reread_env after a change) keeps the fp32 masks, for A/B measurements and tests.
 bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
-    const char *env = getenv("STX_RELU_CODES");
+    const char *env = sw_env("STX_RELU_CODES");
     if (env && atoi(env) == 0) return false;
     if (cfg.id < 200 || cfg.id >= 210 || ksplit > 1) return false;
     const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
     if (xb >= 2147483648.0 || yb >= 2147483648.0) return false;
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     if (force_big && atoi(force_big) == 1) return false;
     return p.epilogue == kEpiForward ? p.in_codes != nullptr
                                      : p.epilogue == kEpiDgrad && p.mask_codes != nullptr;
@@ -988,14 +988,14 @@ bool conv_uses_relu_codes(const ConvConfig &cfg, const ConvProblem &p, int kspli
 // The unsplit eight-wave fp32 kernel and the unsplit fp16-split kernel leave the sign nibbles of their
 // (rectified) output.  Mirrors wino2_launch / h2_launch: no K slices, no tail split, no re-based addressing.
 bool conv_writes_out_codes(const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
-    const char *env = getenv("STX_RELU_CODES");
+    const char *env = sw_env("STX_RELU_CODES");
     if (env && atoi(env) == 0) return false;
     if (p.epilogue != kEpiForward || !p.relu || !p.out_codes || ksplit > 1) return false;
     if (cfg.id >= 300) return true;
     if (cfg.id < 200 || cfg.id >= 210) return false;
     const double xb = 4.0 * p.K * (double)p.H * p.W, yb = 4.0 * p.M * (double)p.H * p.W;
     if (xb >= 2147483648.0 || yb >= 2147483648.0) return false;
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     if (force_big && atoi(force_big) == 1) return false;
     const bool mk = conv_uses_relu_codes(cfg, p, 1);
     const Wino2Tail tail = wino2_tail_split(cfg, p);
@@ -1028,7 +1028,6 @@ static int wino2_launch_tail(hipStream_t s, const ConvConfig &cfg, const ConvPro
                              int epi, const Wino2Tail &tail);
 
 int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
-    if (cfg.id >= 210) return wino4_launch(s, cfg, p, ksplit);
     WinoArgs a;
     a.x = p.x;
     a.w = p.w;
@@ -1056,7 +1055,7 @@ int wino2_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int
     // through descriptors too.  2 GiB and more: the BIG variant, which re-bases its descriptors per
     // chunk / per channel and needs 8 planes (and the pooled output, if fused) under 2 GiB.
     // STX_WINO_BIG=1 forces it on every plane (tests: results must not change).
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     const bool huge = xb >= 2147483648.0 || yb >= 2147483648.0;
     if (wb >= 2147483648.0 || 32.0 * (double)p.H * p.W >= 2147483648.0) {
         set_error("wino2_launch: a %d x %d plane is beyond the buffer-addressing limit", p.H, p.W);
@@ -1158,6 +1157,29 @@ static int wino2_launch_tail(hipStream_t s, const ConvConfig &cfg, const ConvPro
             : cfg.id == 202 ? (wino2_launch_epi<kEpiPartial, 16>(s, part, n_part))
                             : (wino2_launch_epi<kEpiPartial, 32>(s, part, n_part)));
     return splitk_reduce_items_launch(s, p, cfg, tail.slices, n_full, tail.items);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The Winograd configurations of the library (cfg.id >= 200: this kernel; >= 300: conv_h2.hip), by id.
+// (Until round 6 two more fp32 families lived here -- 1-D F(2,3), ids 100+, and the four-wave form of this
+// kernel, ids 210+: reachable only through switches once conv_h2 took the 3x3 layers; they are kept under
+// tools/experiments/ with their tests' history, and this kernel is the library's one fp32 Winograd family.)
+size_t wino_packed_floats(const ConvConfig &cfg, int K, int M) {
+    return cfg.id >= 300 ? h2_packed_floats(K, M) : wino2_packed_floats(K, M);
+}
+
+int wino_pack_weights(hipStream_t s, const float *w_caffe, int Mo, int Ko, int transpose_flip,
+                      const ConvConfig &cfg, float *packed) {
+    if (cfg.id >= 300) return h2_pack_weights(s, w_caffe, Mo, Ko, transpose_flip, packed);
+    return wino2_pack_weights(s, w_caffe, Mo, Ko, transpose_flip, packed);
+}
+
+// Launches a Winograd configuration; `w` must come from wino_pack_weights.
+int wino_launch(hipStream_t s, const ConvConfig &cfg, const ConvProblem &p, int ksplit) {
+    if (cfg.id >= 300) return h2_launch(s, cfg, p, ksplit);
+    if (cfg.id >= 200 && cfg.id < 210) return wino2_launch(s, cfg, p, ksplit);
+    set_error("wino_launch: no kernel for config %d", cfg.id);
+    return STX_ERR_UNSUPPORTED;
 }
 
 }  // namespace stx

@@ -381,49 +381,25 @@ int get_packed(stx_engine *e, int layer, int dir, const ConvConfig &cfg, const f
 static std::mutex g_tuned_mutex;
 static std::map<std::vector<int>, int> g_tuned;
 
-// 3x3 layers with enough channels run a Winograd kernel: 2-D F(2x2,3x3) (4/9 of the direct
-// kernel's MFMAs) when at least half a 64-channel tile is used, else 1-D F(2,3) (2/3).  The
-// choice depends on the shape only, never on timing: the rounding differs between the kernels,
-// and a given shape must always take the same path.  STX_CONV_ALGO=direct|wino1|wino2 (read at
-// every call) overrides it for tests and measurements.
+// 3x3 layers with more than 32 output channels that the fp16-split kernel does not take (h2_choice) run the
+// fp32 2-D Winograd kernel F(2x2,3x3) (4/9 of the direct kernel's MFMAs); everything else the direct kernel.
+// The choice depends on the shape only, never on timing: the rounding differs between the kernels, and a
+// given shape must always take the same path.  STX_CONV_ALGO=direct|wino2|wino2a|wino2b|wino2c overrides it
+// for tests and measurements (a / b / c: one patch geometry only).
 static bool wino_choice(stx_engine *e, int ksize, int K, int M, int H, int W, ConvConfig *out,
                         bool inject = false) {
+    (void)inject;
     if (ksize != 3 || K < 8 || M <= 4) return false;
-    const char *algo = getenv("STX_CONV_ALGO");
+    const char *algo = sw_env("STX_CONV_ALGO");
     if (algo && *algo) {
         if (!strcmp(algo, "direct")) return false;
         if (!strcmp(algo, "wino2")) { *out = wino2_config(wino2_pick_geometry(H, W)); return true; }
         if (!strcmp(algo, "wino2a")) { *out = wino2_config(0); return true; }   // one geometry only
         if (!strcmp(algo, "wino2b")) { *out = wino2_config(1); return true; }
         if (!strcmp(algo, "wino2c")) { *out = wino2_config(2); return true; }
-        if (!strcmp(algo, "wino4")) { *out = wino4_config(wino4_pick_geometry(K, M, H, W)); return true; }
-        if (!strcmp(algo, "wino4old")) { *out = wino4_config(wino2_pick_geometry(H, W)); return true; }
-        if (!strcmp(algo, "wino4a")) { *out = wino4_config(0); return true; }
-        if (!strcmp(algo, "wino4b")) { *out = wino4_config(1); return true; }
-        if (!strcmp(algo, "wino4c")) { *out = wino4_config(2); return true; }
-        if (!strcmp(algo, "wino1")) { *out = wino_config_by_id(M >= 64 ? 0 : 1); return true; }
     }
-    if (!e->winograd) return false;
-    if (M <= 32) {
-        *out = wino_config_by_id(1);
-        return true;
-    }
-    // plane sets of 2 GiB and more: only the eight-wave kernel has the re-based addressing
-    if (4.0 * std::max(K, M) * (double)H * W >= 2147483648.0) {
-        *out = wino2_config(wino2_pick_geometry(H, W));
-        return true;
-    }
-    // Two kernels with identical arithmetic (bit-identical results).  The eight-wave one is a
-    // percent or two faster where both offer the same patch geometry and has the registers to
-    // request everything a loss-injecting epilogue reads at once (the four-wave one spills
-    // there: 0.63 vs 0.44 ms on the 965 x 965 plane of conv1_2's backward pass); the four-wave
-    // one has a third patch geometry (8 x 32 pixels), which decides on the small odd planes of
-    // a pyramid (91 x 91, 46 x 46: fewer, fuller rounds of workgroups).  Model cost of the best
-    // geometry of each, with those handicaps.  Shape only, never timing.
-    const int g4 = wino4_pick_geometry(K, M, H, W), g2 = wino2_pick_geometry(H, W);
-    const double t4 = wino4_geometry_cost(g4, K, M, H, W) * (inject ? 1.12 : 1.02);
-    const double t2 = wino4_geometry_cost(g2, K, M, H, W);
-    *out = t4 < t2 ? wino4_config(g4) : wino2_config(g2);
+    if (!e->winograd || M <= 32) return false;
+    *out = wino2_config(wino2_pick_geometry(H, W));
     return true;
 }
 
@@ -516,7 +492,7 @@ static bool conv_writes_pool_codes(const ConvConfig &cfg) { return (cfg.id >= 20
 // True if a launch of `p` under `cfg` writes p.pool_out itself (2-D Winograd, no K split).
 static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
     // (STX_POOL_FWD_FUSE=0: the stand-alone pooling kernel everywhere, for A/B measurements and tests)
-    const char *env = getenv("STX_POOL_FWD_FUSE");
+    const char *env = sw_env("STX_POOL_FWD_FUSE");
     if (env && atoi(env) == 0) return false;
     if (cfg.id >= 300) return conv_splitk_factor(cfg, p, true) == 1 && h2_fuses_pool(p);
     return cfg.id >= 200 && conv_splitk_factor(cfg, p, true) == 1 && wino2_fuses_pool(p);
@@ -535,17 +511,17 @@ static bool conv_fuses_pool(const ConvConfig &cfg, const ConvProblem &p) {
 // STX_CONV_ALGO=h2|h2a|h2b|h2c forces the kernel (any / the 64- / the 128-channel / the two-patch tiling)
 // wherever it applies.
 static bool h2_enabled() {
-    const char *algo = getenv("STX_CONV_ALGO");
+    const char *algo = sw_env("STX_CONV_ALGO");
     if (algo && *algo) return !strncmp(algo, "h2", 2);
     // (the thresholds of h2_choice: with STX_CONV_H2=0 and no STX_CONV_H2_BWD neither direction takes the kernel)
-    const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
+    const char *env = sw_env("STX_CONV_H2"), *envb = sw_env("STX_CONV_H2_BWD");
     const int fwd_min = env ? atoi(env) : 64;
     const int bwd_min = envb ? atoi(envb) : (env && atoi(env) <= 0 ? 0 : 64);
     return fwd_min > 0 || bwd_min > 0;
 }
 
 static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
-    const char *algo = getenv("STX_CONV_ALGO");
+    const char *algo = sw_env("STX_CONV_ALGO");
     int force = 0;
     if (algo && *algo) {
         if (!strcmp(algo, "h2")) force = 4;
@@ -554,7 +530,7 @@ static bool h2_choice(const ConvProblem &p, ConvConfig *out) {
         else if (!strcmp(algo, "h2c")) force = 3;
         else return false;             // some other kernel family was asked for
     }
-    const char *env = getenv("STX_CONV_H2"), *envb = getenv("STX_CONV_H2_BWD");
+    const char *env = sw_env("STX_CONV_H2"), *envb = sw_env("STX_CONV_H2_BWD");
     const int min_k = p.epilogue == kEpiForward ? (env ? atoi(env) : 64)
                                                 : (envb ? atoi(envb) : env && atoi(env) <= 0 ? 0 : 64);
     if (!force && (min_k <= 0 || p.K < min_k || p.M < 64)) return false;
@@ -716,7 +692,7 @@ static ConvProblem conv_backward_shape(stx_engine *e, int li) {
 // Then the pooling layer's backward kernel does not run, and the gradient of the convolution's output
 // blob (four times the pooled one) is neither written nor read.  STX_POOL_BWD_FUSE=0 keeps the kernel.
 static bool conv_backward_takes_pooled(stx_engine *e, int li) {
-    const char *env = getenv("STX_POOL_BWD_FUSE");
+    const char *env = sw_env("STX_POOL_BWD_FUSE");
     if (env && atoi(env) == 0) return false;
     const ConvProblem p = conv_backward_shape(e, li);
     ConvConfig cfg;
@@ -1020,9 +996,54 @@ int quiesce_members(stx_engine *e) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// ---- the switches' snapshot (common.h: sw_env).  Old snapshots are never freed: a thread may still hold a
+// pointer into one, and a snapshot is a few hundred bytes.
+namespace stx {
+namespace {
+typedef std::map<std::string, std::string> SwitchMap;
+std::atomic<const SwitchMap *> g_switches{nullptr};
+std::mutex g_switches_mutex;
+extern "C" char **environ;
+
+const SwitchMap *switches_snapshot() {
+    auto *m = new SwitchMap;
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "STX_", 4) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (eq) (*m)[std::string(*e, eq - *e)] = eq + 1;
+    }
+    return m;
+}
+}  // namespace
+
+void sw_reread() {
+    std::lock_guard<std::mutex> lock(g_switches_mutex);
+    g_switches.store(switches_snapshot(), std::memory_order_release);
+}
+
+const char *sw_env(const char *name) {
+    const SwitchMap *m = g_switches.load(std::memory_order_acquire);
+    if (!m) {
+        std::lock_guard<std::mutex> lock(g_switches_mutex);
+        m = g_switches.load(std::memory_order_acquire);
+        if (!m) {
+            m = switches_snapshot();
+            g_switches.store(m, std::memory_order_release);
+        }
+    }
+    auto it = m->find(name);
+    return it == m->end() ? nullptr : it->second.c_str();
+}
+}  // namespace stx
+
 extern "C" {
 
 const char *stx_version(void) { return "libstx 0.1 (gfx950)"; }
+
+int stx_reread_env(void) {
+    stx::sw_reread();
+    return STX_OK;
+}
 
 const char *stx_last_error(void) { return g_error.c_str(); }
 
@@ -1205,9 +1226,9 @@ static int build_engine(int device, const stx_layer_desc *layers, int n_layers,
     }
     STX_HIP(hipEventCreate(&e->ev_tune0));
     STX_HIP(hipEventCreate(&e->ev_tune1));
-    if (const char *env = getenv("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
-    if (const char *env = getenv("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
-    if (const char *env = getenv("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
+    if (const char *env = sw_env("STX_AUTOTUNE")) e->autotune = atoi(env) != 0;
+    if (const char *env = sw_env("STX_POOL_CODES")) e->pool_codes = atoi(env) != 0;
+    if (const char *env = sw_env("STX_WINOGRAD")) e->winograd = atoi(env) != 0;
     e->scalars_cap = kScalarFloats;
     for (stx_engine::ScalarArena &a : e->arena) {
         STX_TRY(a.scalars.ensure(e->scalars_cap * sizeof(float)));
@@ -1673,7 +1694,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
     // The final sums of the loss terms (two per style term, two per content term) are collected and run
     // as ONE launch behind the forward pass (STX_SUMS_LATE=0: each where it arises, as rounds 1-4 did);
     // what they add up must outlive the term's own launches: one scratch region per style term.
-    const bool sums_late = !(getenv("STX_SUMS_LATE") && !atoi(getenv("STX_SUMS_LATE")));
+    const bool sums_late = !(sw_env("STX_SUMS_LATE") && !atoi(sw_env("STX_SUMS_LATE")));
     std::vector<SumJob> sum_jobs;
     size_t scratch_used = 0;
     if (sums_late) {
@@ -1789,7 +1810,7 @@ int sc_grad_run(stx_engine *e, const TileCall &c, const TilePlan &plan, PendingL
         return STX_OK;
     };
     // (STX_TERMS_LATE=1: all loss terms after the forward pass, for A/B measurements)
-    const bool interleave = !(getenv("STX_TERMS_LATE") && atoi(getenv("STX_TERMS_LATE")));
+    const bool interleave = !(sw_env("STX_TERMS_LATE") && atoi(sw_env("STX_TERMS_LATE")));
     const std::function<int(int)> hook = [&](int blob) -> int {
         const int k = tap_of[blob];
         return k >= 0 ? launch_terms((size_t)k) : STX_OK;

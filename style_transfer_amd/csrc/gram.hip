@@ -39,8 +39,8 @@ GramPlan gram_plan(int C, int HW) {
     const int T = ceil_div(C, kGT);
     p.tiles = T * (T + 1) / 2;
     int target = 512, min_stages = 8;
-    if (const char *env = getenv("STX_GRAM_WGS")) target = std::max(1, atoi(env));
-    if (const char *env = getenv("STX_GRAM_MIN_STAGES")) min_stages = std::max(1, atoi(env));
+    if (const char *env = sw_env("STX_GRAM_WGS")) target = std::max(1, atoi(env));
+    if (const char *env = sw_env("STX_GRAM_MIN_STAGES")) min_stages = std::max(1, atoi(env));
     int splits = std::max(1, target / p.tiles);
     splits = std::min(splits, ceil_div(HW, min_stages * kGP));   // at least eight stages per slice
     splits = std::max(splits, 1);
@@ -647,15 +647,15 @@ __global__ __launch_bounds__(256, 2) void gram_partial_h2_kernel(const float *__
     }
 }
 
-// STX_GRAM=fp32 (read at every call) keeps the fp32-MFMA kernels, =bf3 the three-piece bf16 kernel,
+// STX_GRAM=fp32 (stx_reread_env after a change) keeps the fp32-MFMA kernels, =bf3 the three-piece bf16 kernel,
 // for A/B measurements and tests.
 static bool gram_use_bf3() {
-    const char *env = getenv("STX_GRAM");
+    const char *env = sw_env("STX_GRAM");
     return !(env && !strcmp(env, "fp32"));
 }
 
 bool gram_h2_usable(const float *feat, int C, int HW) {
-    const char *env = getenv("STX_GRAM");
+    const char *env = sw_env("STX_GRAM");
     if (env && (!strcmp(env, "fp32") || !strcmp(env, "bf3"))) return false;
     return (reinterpret_cast<uintptr_t>(feat) & 3) == 0 && 4.0 * C * (double)HW < 2147483648.0;
 }
@@ -679,7 +679,7 @@ int gram_partials_launch(hipStream_t s, const float *feat, const GramPlan &plan,
         return STX_OK;
     }
     // (buffer loads need dword alignment only: odd plane sizes take the wide kernel too)
-    if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && !getenv("STX_GRAM_NARROW")) {
+    if ((reinterpret_cast<uintptr_t>(feat) & 3) == 0 && bytes < 2147483648.0 && !sw_env("STX_GRAM_NARROW")) {
         gram_partial_wide_kernel<<<plan.tiles * plan.splits, 256, 0, s>>>(
             feat, plan.C, plan.HW, plan.tiles, slice, (unsigned)bytes, partials);
         STX_CHECK_LAUNCH();

@@ -454,7 +454,7 @@ __global__ void symm_split_kernel(const float *__restrict__ dsym, int C, int Cp,
 int symm_num_workgroups(int C, int HW) { return ceil_div(C, kSM) * ceil_div(HW, kSN); }
 
 bool symm_bf3_usable(const float *feat, const float *out, int C, int HW) {
-    const char *env = getenv("STX_SYMM");
+    const char *env = sw_env("STX_SYMM");
     if (env && !strcmp(env, "fp32")) return false;
     // (16 planes must stay under 2 GiB: the reach of one step's loads in the BIG variant)
     return 64.0 * (double)HW < 2147483648.0 &&
@@ -470,7 +470,7 @@ int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigne
     }
     const int m_tiles = Cp / kSM;
     const double bytes = 4.0 * C * (double)HW;
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     if (bytes >= 2147483648.0 || (force_big && atoi(force_big) == 1))
         symm_bf3_kernel<true><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, pieces, out, partials, C, Cp,
                                                                        HW, 0u, m_tiles);
@@ -481,9 +481,9 @@ int symm_bf3_launch(hipStream_t s, const float *feat, const float *dsym, unsigne
     return STX_OK;
 }
 
-// STX_SYMM=bf3 keeps the three-piece bf16 kernel, =fp32 the fp32-MFMA path (read at every call)
+// STX_SYMM=bf3 keeps the three-piece bf16 kernel, =fp32 the fp32-MFMA path (stx_reread_env after a change)
 bool symm_h2_usable(const float *feat, const float *out, int C, int HW) {
-    const char *env = getenv("STX_SYMM");
+    const char *env = sw_env("STX_SYMM");
     if (env && (!strcmp(env, "fp32") || !strcmp(env, "bf3"))) return false;
     return C % 4 == 0 && symm_bf3_usable(feat, out, C, HW);
 }
@@ -493,7 +493,7 @@ int symm_h2_launch(hipStream_t s, const float *feat, const float *dsym, const un
     const int Cp = ceil_div(C, kSM) * kSM;
     const int m_tiles = Cp / kSM;
     const double bytes = 4.0 * C * (double)HW;
-    const char *force_big = getenv("STX_WINO_BIG");
+    const char *force_big = sw_env("STX_WINO_BIG");
     if (bytes >= 2147483648.0 || (force_big && atoi(force_big) == 1))
         symm_h2_kernel<true><<<symm_num_workgroups(C, HW), 256, 0, s>>>(feat, dsym, d_amax, n_damax, f_amax, out,
                                                                       partials, C, Cp, HW, 0u, m_tiles);

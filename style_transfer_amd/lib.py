@@ -57,6 +57,7 @@ class Tap(ctypes.Structure):
 # name -> argtypes; every function returns int status except the three noted below.
 _vp, _i, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
 SIGNATURES = {
+    'stx_reread_env': [],
     'stx_device_count': [c_int_p],
     'stx_device_name': [_i, ctypes.c_char_p, _sz],
     'stx_engine_create': [_i, ctypes.POINTER(LayerDesc), _i, ctypes.POINTER(_vp)],
@@ -149,6 +150,14 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise StxError(name, rc, lib.stx_last_error().decode('utf-8', 'replace'))
+
+
+def reread_env():
+    """The library reads its STX_* switches from a snapshot of the environment (stx_reread_env): call this after
+    changing one inside a running process.  A no-op while the library is not loaded (its first use takes the
+    snapshot)."""
+    if _lib is not None:
+        call('stx_reread_env')
 
 
 def device_count():

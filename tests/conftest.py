@@ -28,3 +28,30 @@ def _gpu_guard(request):
     if request.node.get_closest_marker('gpu') is not None:
         from tests.gpu_helpers import require_gpu
         require_gpu()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_monkeypatch(monkeypatch):
+    """libstx reads its STX_* switches from a snapshot of the environment (stx_reread_env), not with
+    getenv() at every launch: a test that sets or deletes one through `monkeypatch` gets a fresh snapshot
+    with it, and another one when the environment is restored at the end of the test."""
+    from style_transfer_amd import lib
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+    touched = []
+
+    def setenv_and_reread(name, value, *args, **kwargs):
+        setenv(name, value, *args, **kwargs)
+        if name.startswith('STX_'):
+            touched.append(name)
+            lib.reread_env()
+
+    def delenv_and_reread(name, *args, **kwargs):
+        delenv(name, *args, **kwargs)
+        if name.startswith('STX_'):
+            touched.append(name)
+            lib.reread_env()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reread, delenv_and_reread
+    yield
+    if touched:
+        monkeypatch.undo()
+        lib.reread_env()

@@ -141,19 +141,23 @@ FP32_KERNELS = {'STX_CONV_H2': '0', 'STX_GRAM': 'fp32', 'STX_SYMM': 'fp32'}
 
 
 class fp32_kernels:
-    """Within the block the library takes its fp32-MFMA kernels only (the switches are read at every
-    call): no fp16-split convolution, Gram or SYMM -- round 4's arithmetic."""
+    """Within the block the library takes its fp32-MFMA kernels only (a new snapshot of the switches on the
+    way in and out: stx_reread_env): no fp16-split convolution, Gram or SYMM -- round 4's arithmetic."""
 
     def __enter__(self):
+        from style_transfer_amd import lib
         self.old = {k: os.environ.get(k) for k in FP32_KERNELS}
         os.environ.update(FP32_KERNELS)
+        lib.reread_env()
 
     def __exit__(self, *exc):
+        from style_transfer_amd import lib
         for k, v in self.old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        lib.reread_env()
 
 
 def check_tile(eng, om, tile, start, roll, cl, cw, sl, sw, lw, ref_grad=None, flip_l2=1e-2,

@@ -157,7 +157,7 @@ def test_conv_at_real_layer_shapes(cin, cout, h, w):
 @pytest.mark.parametrize('cin,cout,h,w', [(512, 512, 91, 91), (256, 256, 181, 181), (256, 512, 91, 91)])
 def test_tail_split_changes_the_summation_order_only(cin, cout, h, w, monkeypatch):
     """Launches of 256 q + r work items run their last r items as K slices (conv_wino2.hip: tail split).
-    With it and without it (STX_WINO2_TAIL=0, read at every call) the layer must agree to the kernel
+    With it and without it (STX_WINO2_TAIL=0) the layer must agree to the kernel
     tolerance -- and must NOT agree bit for bit on these shapes, or the path under test did not run.
     (The fp32 kernel's schedule: the fp16-split kernel, which takes these shapes by default, is off.)"""
     monkeypatch.setenv('STX_CONV_H2', '0')

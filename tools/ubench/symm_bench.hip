@@ -13,6 +13,8 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
     fputc('\n', stderr);
 }
+const char *sw_env(const char *name) { return getenv(name); }     // (the harness reads the environment as it is)
+void sw_reread() {}
 }  // namespace stx
 
 int main() {

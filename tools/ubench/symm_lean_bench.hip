@@ -17,6 +17,8 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
     fputc('\n', stderr);
 }
+const char *sw_env(const char *name) { return getenv(name); }     // (the harness reads the environment as it is)
+void sw_reread() {}
 int splitk_reduce_launch(hipStream_t, const ConvProblem &, int) { return 0; }
 }  // namespace stx
 

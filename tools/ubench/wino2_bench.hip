@@ -1,7 +1,7 @@
 // Standalone timing harness for conv_wino2.hip (tuning aid, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I style_transfer_amd/csrc \
-//         [-DSTX_WINO2_TIMING] tools/ubench/wino2_bench.hip style_transfer_amd/csrc/conv_wino4.hip \
-//         -o /tmp/wino2_bench
+//         [-DSTX_WINO2_TIMING] tools/ubench/wino2_bench.hip -o /tmp/wino2_bench
+// (the four-wave form, ALGO=4, left the library in round 6: tools/experiments/conv_wino4.hip)
 // With STX_WINO2_TIMING the kernel accumulates, per wave of workgroup 0, the core-clock cycles
 // spent in its compute segments, hand-over segments and barrier waits; the harness prints them.
 #include "../../style_transfer_amd/csrc/conv_wino2.hip"
@@ -23,6 +23,8 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
     fputc('\n', stderr);
 }
+const char *sw_env(const char *name) { return getenv(name); }     // (the harness reads the environment as it is)
+void sw_reread() {}
 int splitk_reduce_launch(hipStream_t, const ConvProblem &, int) { return 0; }
 }  // namespace stx
 
@@ -60,8 +62,7 @@ static void run(int K, int M, int H, int W, int epilogue) {
     p.x = x, p.w = w, p.y = y, p.bias = nullptr, p.mask = epilogue == kEpiDgrad ? mask : nullptr;
     p.K = K, p.M = M, p.H = H, p.W = W, p.ksize = 3, p.relu = 1, p.epilogue = epilogue;
     const int geo = getenv("GEO") ? atoi(getenv("GEO")) : wino2_pick_geometry(H, W);
-    // ALGO=4: the four-wave kernel (conv_wino4.hip, linked as its own translation unit)
-    const ConvConfig cfg = getenv("ALGO") && atoi(getenv("ALGO")) == 4 ? wino4_config(geo) : wino2_config(geo);
+    const ConvConfig cfg = wino2_config(geo);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) wino2_launch(0, cfg, p, 1);
