@@ -439,6 +439,9 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     };
 
     // ---- prologue
+#ifdef STX_H2_TIMING
+    const long long t_p0 = clock64();          // index setup, descriptors, scales done
+#endif
     static_for<0, NU>([&](auto n_c) __attribute__((always_inline)) { x_load(decltype(n_c)::value, c_begin); });
     if (LEAN) {
         a_load(0, 0, c_begin);
@@ -552,11 +555,21 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         }
     };
     if (HOIST) content_columns(rows0);
+#ifdef STX_H2_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t_p1 = clock64();          // first loads requested, epilogue addresses set up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_p2 = clock64();          // ... and landed
+#endif
     static_for<0, NU>([&](auto n_c) __attribute__((always_inline)) {
         constexpr int n = decltype(n_c)::value;
         stage_all(n, 0);
         if (c_begin + 1 < c_end) x_load(n, c_begin + 1);
     });
+#ifdef STX_H2_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t_p3 = clock64();          // first chunk staged
+#endif
     lds_barrier();
     b_read(0, 0, 0);
 
@@ -850,6 +863,7 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
         g_h2_timing[wave][3] = w_loop - w_start, g_h2_timing[wave][4] = w_end - w_loop;
         g_h2_timing[wave][5] = wall_clock64() - w_end;
         for (int i = 0; i < 4; ++i) g_h2_epi[wave][i] = t_epi[i] - t_end;
+        g_h2_epi[wave][4] = t_p0 - t_start, g_h2_epi[wave][5] = t_p1 - t_p0, g_h2_epi[wave][6] = t_p2 - t_p1, g_h2_epi[wave][7] = t_p3 - t_p2;
     }
 #endif
 }

@@ -228,6 +228,8 @@ static void run(int K, int M, int H, int W, int mb, int backward) {
                t[wv][5] / 100.0, (double)t[wv][1] / (t[wv][4] / 100.0));
     long long te[8][8];
     hipMemcpyFromSymbol(te, HIP_SYMBOL(stx::g_h2_epi), sizeof(te));
+    printf("   prologue: setup %lld, loads requested + epilogue addresses %lld, wait for the loads %lld, first staging %lld, barrier + first B read %lld\n",
+           te[0][4], te[0][5], te[0][6], te[0][7], t[0][0] - te[0][4] - te[0][5] - te[0][6] - te[0][7]);
     printf("   epilogue pass 0, cycles after the loop: loads issued %lld, through the first barrier %lld, exchange written + barrier %lld, pass done %lld\n",
            te[0][0], te[0][1], te[0][2], te[0][3]);
 #endif
