@@ -262,7 +262,8 @@ def test_config4_miniature_matches_reference_run(golden, kernels):
     assert diff.max() < 2.0 and diff.mean() < 0.02, (diff.max(), diff.mean())
 
 
-def test_lbfgs_multi_tile_run_at_a_stable_size_matches_reference_run(golden):
+@pytest.mark.parametrize('kernels', ['fp32', 'default'])
+def test_lbfgs_multi_tile_run_at_a_stable_size_matches_reference_run(golden, kernels):
     """The L-BFGS pin at a size where ONE reference trajectory exists (make_golden.py
     section 4j): VGG-19 with AVE pooling x L-BFGS x a ragged 2 x 2 tiling of 97 .. 140-pixel tiles, 3 + 2
     iterations.  tests/golden/branch_sets.py stable: under every other float32 implementation of the
@@ -272,7 +273,7 @@ def test_lbfgs_multi_tile_run_at_a_stable_size_matches_reference_run(golden):
     2e-4 at step 2 and 2.4e-3 at step 5 between its own SGEMM and torch's conv2d.)  The final picture still
     carries the ReLU near-ties of five steps as displaced patches (the reference against itself: max 9 .. 20,
     mean 0.01 .. 0.07): bounded in the mean."""
-    got, raw, evals = _run_fixture(golden, 'e2e_stable', ['style_u8'], 'default')
+    got, raw, evals = _run_fixture(golden, 'e2e_stable', ['style_u8'], kernels)       # (both kernel sets: one trajectory)
     assert evals == 4 * (3 + 1) + 4 * (2 + 1)
     ref = golden['e2e_stable.log']
     assert got.shape == ref.shape
