@@ -152,3 +152,75 @@ def test_schedule_is_planned_up_front():
     args = config_system.parse_args(None, ['-ci', 'c', '-si', 's', '--style-multiscale', '100',
                                            '400'], config_py=False)
     assert transfer.style_pyramid(args) == [400, 283, 200, 141, 100]
+
+
+def test_bench_per_kernel_accounting():
+    """bench.py's roofline.per_kernel: launch groups are sorted into kernels by layer shape and tap, an
+    fp16-split layer issues 2 x its direct FLOP count, fractions are taken against the fp16 MFMA peak."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('stx_bench', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules['stx_bench'] = bench
+    spec.loader.exec_module(bench)
+    net = netspec.builtin_net('vgg19')
+    chans, scale, c_in, s = {}, {}, 3, 1
+    for lay in net.as_dicts():
+        if lay['type'] == 'Convolution':
+            chans[lay['top']], scale[lay['top']], c_in = (c_in, lay['num_output']), s, lay['num_output']
+        elif lay['type'] == 'Pooling':
+            s *= 2
+    convs = [l for l in chans if int(l[4]) < 5 or l == 'conv5_1']
+
+    class Array:
+        def free(self):
+            pass
+
+    class Eng:
+        def __init__(self):
+            self.reads = 0
+
+        def to_device(self, host):
+            return Array()
+
+        def empty(self, shape):
+            return Array()
+
+        def sc_grad_tile_async(self, *args, **kwargs):
+            pass
+
+        def sync(self):
+            pass
+
+        def profile(self, on):
+            pass
+
+        def layer_info(self, layer):
+            return scale[layer], chans[layer][1]
+
+        def profile_read(self):
+            rows = []
+            for kind in ('fwd', 'bwd'):
+                for l in (convs if kind == 'fwd' else convs[::-1]):
+                    cin, cout = chans[l]
+                    rows.append(('%s %s' % (kind, l), 0.1, 18.0 * cin * cout * (bench.TILE // scale[l]) ** 2))
+            return rows + [('gram conv1_1', 0.05, 8.6e9), ('sums', 0.01, 0.0)]
+
+    class Job:
+        eng = Eng()
+    rec = bench.kernel_records(Job(), reps=2)
+    groups = {g['name']: g for g in rec['groups']}
+    fwd = next(g for n, g in groups.items() if n.startswith('forward 3x3 layers from 128'))
+    bwd = next(g for n, g in groups.items() if n.startswith('backward 3x3 layers from 128'))
+    inj = next(g for n, g in groups.items() if n.startswith('loss-injecting backward'))
+    assert (fwd['launch_groups'], bwd['launch_groups'], inj['launch_groups']) == (10, 6, 4)
+    direct = sum(18.0 * chans[l][0] * chans[l][1] * (1024 // scale[l]) ** 2 for l in convs
+                 if min(chans[l]) >= 128)
+    assert fwd['flop_issued_fp16'] == pytest.approx(2 * direct)
+    assert fwd['frac_fp16_pipe'] == pytest.approx(2 * direct / 1e-3 / 1e12 / (16 * 157.3), rel=1e-6)
+    assert rec['dominant'] is fwd and groups['loss terms, pooling, copies']['launch_groups'] == 2
+    shallow = [n for n in groups if n.startswith('64-channel layers')]
+    assert sorted(n.split(': ')[1].split(' (')[0] for n in shallow) == ['bwd conv1_2', 'bwd conv2_1', 'fwd conv1_2', 'fwd conv2_1']
+    assert groups['first layer / backward into the image (fp32 MFMA)']['launch_groups'] == 2
+    assert rec['tile_ms_single_stream'] == pytest.approx(0.1 * 2 * len(convs) + 0.06)
