@@ -142,49 +142,66 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     const int xi = wave & 3, wh = wave >> 2;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // XCD-aware work order, see conv_wino2.hip
-    const int m_tiles = a.m_tiles;
+    // XCD-aware work order, see conv_wino2.hip.  (Round 6: every kernel argument the index arithmetic in front
+    // of the first loads needs is fetched in ONE batch -- the empty asm pins them here.  Read where they are used
+    // they came in six dependent batches of scalar loads, each waited for, and the input's maximum, which no
+    // load needs, in four more in front of the first patch load: a workgroup's prologue 9.4 k -> 5.9 k cycles,
+    // the kernels 2 .. 5 % -- profiles/r06_h2_prologue_stamps.txt, r06_h2_early_args_ab.txt.)
+    const int m_tiles = a.m_tiles, a_tiles_x = a.tiles_x, a_tiles_y = a.tiles_y, a_H = a.H, a_W = a.W;
+    const int a_n_chunks = a.n_chunks, a_ksplit = a.ksplit, a_item_base = a.item_base, a_x_bytes = a.x_bytes,
+              a_w_bytes = a.w_bytes;
+    const float *const a_x = a.x, *const a_w = a.w;
+    asm volatile("" ::"s"(m_tiles), "s"(a_tiles_x), "s"(a_tiles_y), "s"(a_H), "s"(a_W), "s"(a_n_chunks), "s"(a_ksplit),
+                 "s"(a_item_base), "s"(a_x_bytes), "s"(a_w_bytes), "s"(a_x), "s"(a_w));
     const int nb = gridDim.x, xcd = blockIdx.x & 7, slot_x = blockIdx.x >> 3;
     const int q8 = nb >> 3, r8 = nb & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_x;
-    const int kslice = sgpr(EPI == kEpiPartial ? L % a.ksplit : 0);
-    const int Lt = sgpr(EPI == kEpiPartial ? a.item_base + L / a.ksplit : L);
+    const int kslice = sgpr(EPI == kEpiPartial ? L % a_ksplit : 0);
+    const int Lt = sgpr(EPI == kEpiPartial ? a_item_base + L / a_ksplit : L);
     int ptile, mtile;
-    wino2_item_tiles(Lt, m_tiles, a.tiles_x * a.tiles_y, ptile, mtile);
+    wino2_item_tiles(Lt, m_tiles, a_tiles_x * a_tiles_y, ptile, mtile);
     ptile = sgpr(ptile);
     mtile = sgpr(mtile);
     // (K slices are whole pairs of chunks: the chunk loop below runs two per trip)
-    const int c_begin = sgpr(EPI == kEpiPartial ? 2 * (kslice * (a.n_chunks >> 1) / a.ksplit) : 0);
-    const int c_end = sgpr(EPI == kEpiPartial ? 2 * ((kslice + 1) * (a.n_chunks >> 1) / a.ksplit) : a.n_chunks);
-    const int y0 = sgpr((ptile / a.tiles_x) * PR);
-    const int x0 = sgpr((ptile % a.tiles_x) * PC);
+    const int c_begin = sgpr(EPI == kEpiPartial ? 2 * (kslice * (a_n_chunks >> 1) / a_ksplit) : 0);
+    const int c_end = sgpr(EPI == kEpiPartial ? 2 * ((kslice + 1) * (a_n_chunks >> 1) / a_ksplit) : a_n_chunks);
+    const int y0 = sgpr((ptile / a_tiles_x) * PR);
+    const int x0 = sgpr((ptile % a_tiles_x) * PC);
     const int m0 = mtile * BM;
-    const int HW = a.H * a.W;
+    const int HW = a_H * a_W;
     const unsigned HW4 = (unsigned)HW * 4u;
     // PIN: the pooled plane the input is given on (ceil mode)
-    const int pih = (a.H + 1) >> 1, piw = (a.W + 1) >> 1;
+    const int pih = (a_H + 1) >> 1, piw = (a_W + 1) >> 1;
     const unsigned XP4 = PIN ? (unsigned)(pih * piw) * 4u : HW4;      // bytes of one input plane
 
     constexpr unsigned kOob = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x), 0, a.x_bytes, 0x00020000);
+        const_cast<float *>(a_x), 0, a_x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.w), 0, a.w_bytes, 0x00020000);
+        const_cast<float *>(a_w), 0, a_w_bytes, 0x00020000);
     // (three code bytes are fetched as one dword at any byte offset: the range ends 3 bytes behind the array)
     const __amdgpu_buffer_rsrc_t rcx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(a.pin_codes), 0, PIN ? (a.x_bytes >> 2) + 3 : 0, 0x00020000);
+        const_cast<unsigned char *>(a.pin_codes), 0, PIN ? (a_x_bytes >> 2) + 3 : 0, 0x00020000);
 
-    // ---- scales: the input's from the maximum its producer left, the bank's from its header
-    unsigned amax_bits = 0;
+    // ---- scales: the input's from the maximum its producer left, the bank's from its header -- read behind the
+    // first loads' requests (read_scales, in the prologue): only the staging needs them
+    float sv = 0.f, out_scale = 0.f, out_scale2 = 0.f;
+    auto read_scales = [&]() __attribute__((always_inline)) {
+        // (read-only in this launch and wave-uniform: the constant address space makes them scalar loads wherever
+        // the block stands -- behind the first vector loads the compiler turned them into sixteen 16-byte VMEM loads)
+        typedef const __attribute__((address_space(4))) unsigned *kconst_u32;
+        const kconst_u32 slots = (kconst_u32)(uintptr_t)a.x_amax, header = (kconst_u32)(uintptr_t)a_w;
+        unsigned amax_bits = 0;
 #pragma unroll
-    for (int i = 0; i < kAmaxSlots; ++i) amax_bits = max(amax_bits, a.x_amax[i]);
-    const int es = sgpr(h2_scale_exp(amax_bits));
-    const int ew = sgpr(reinterpret_cast<const int *>(a.w)[(a.w_bytes >> 2) + 1]);
-    const float sv = pow2f(es);
-    // (both scales undone exactly: 2^-(es + ew) in two factors when it leaves the normal range -- a blob whose
-    // maximum is below 2^-99 with a bank exponent near 14; the second factor is 1 otherwise)
-    const int eo = -es - ew, eo1 = eo < -126 ? -126 : eo > 127 ? 127 : eo;
-    const float out_scale = pow2f(eo1), out_scale2 = pow2f(eo - eo1);
+        for (int i = 0; i < kAmaxSlots; ++i) amax_bits = max(amax_bits, slots[i]);
+        const int es = sgpr(h2_scale_exp(amax_bits));
+        const int ew = sgpr((int)header[(a_w_bytes >> 2) + 1]);
+        sv = pow2f(es);
+        // (both scales undone exactly: 2^-(es + ew) in two factors when it leaves the normal range -- a blob
+        // whose maximum is below 2^-99 with a bank exponent near 14; the second factor is 1 otherwise)
+        const int eo = -es - ew, eo1 = eo < -126 ? -126 : eo > 127 ? 127 : eo;
+        out_scale = pow2f(eo1), out_scale2 = pow2f(eo - eo1);
+    };
 
     // ---- staging role.  The V array of a chunk has RT positions (a row of the patch, an x-tile) x 16
     // channels.  Positions 0 .. 128 FULL - 1: a unit = one position x four channels (quad), every thread
@@ -449,6 +466,8 @@ __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) a_load(ky, ky, c_begin);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    read_scales();
 #pragma unroll
     for (int b = 0; b < MB; ++b)
 #pragma unroll
