@@ -128,7 +128,7 @@ __device__ long long g_h2_epi[8][8];     // epilogue, pass 0: loads issued, firs
 template <int EPI, int MB, int PB, int PIN>
 __global__ __launch_bounds__(NT) void conv_h2_kernel(WinoArgs a) {
     using G = Geo<PB>;
-    constexpr int PR = G::PR, RT = G::RT, V_PIECE = G::V_PIECE, V_BYTES = G::V_BYTES, NU = G::NU, FULL = G::FULL;
+    [[maybe_unused]] constexpr int PR = G::PR, RT = G::RT, V_PIECE = G::V_PIECE, V_BYTES = G::V_BYTES, NU = G::NU, FULL = G::FULL;
     constexpr size_t kLdsBytes = G::kLds;
     constexpr int NJ = 4 * PB;                  // pixel blocks of 32 positions
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
